@@ -1,0 +1,134 @@
+/*
+ * hydrocol.h -- C-ABI of libhydrocol.so: MI355X (gfx950) ensemble stepper for the
+ * HydroModel 1-D stochastic Richards soil column.
+ *
+ * The reference (vrettasm/HydroModel) is pure Python and has no FFI; the boundary it
+ * exposes for this path is two Python call signatures.  Each entry point below names
+ * the reference interface it replaces (paths relative to /root/reference/code):
+ *
+ *   hc_set_column      <- objects built by Simulation.setupModel (src/simulation.py:100-231):
+ *                         Porosity / TreeRoots / VrettasFung|vanGenuchten / SoilProperties ...
+ *                         flattened to per-depth tables by hydromodel_amd/digest.py
+ *   hc_set_forcing     <- per-row args_i dict (src/simulation.py:591-602): precipitation, atm,
+ *                         time(hour), wtd; refresh rule `precip > 0.5 or i % 48 == 0` (:599)
+ *   hc_set_state/get   <- y0 / y_i vectors (src/simulation.py:514,609,626)
+ *   hc_set_noise_*     <- n_rnd vectors drawn at src/simulation.py:426,561,601
+ *   hc_step_rows       <- the row loop body: RichardsPDE.solve(t_span, y0, args_i)
+ *                         (src/richards_pde.py:478-537 -> scipy solve_ivp BDF) followed by
+ *                         find_wtd(y_i >= psi_sat) (src/simulation.py:609-612)
+ *   hc_rhs             <- RichardsPDE.__call__(t, y, args)   (src/richards_pde.py:82-160)
+ *   hc_model_nodes     <- h_model(y_i, z, args_i) diagnostics call (src/simulation.py:623;
+ *                         src/models/vrettas_fung.py:51 / vanGenuchten.py:23)
+ *   hc_get_moments     <- (new) per-row ensemble moments of wtd_est (src/simulation.py:612)
+ *
+ * Conventions: every function returns 0 on success or a negative hc_status; nothing throws
+ * or aborts across the boundary; hc_last_error() gives the thread-local message.  Host
+ * pointers are only read/written during the call.  The library owns all device memory.
+ * State layout in HBM is member-major: psi[member][depth], fp64.  One handle drives one
+ * device; a handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef HYDROCOL_H
+#define HYDROCOL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hc_handle hc_handle;
+
+enum hc_status {
+    HC_OK = 0,
+    HC_ERR_ARG = -1,       /* bad argument / call order            */
+    HC_ERR_DEVICE = -2,    /* HIP runtime error                    */
+    HC_ERR_NO_DEVICE = -3, /* no gfx950 device visible             */
+    HC_ERR_UNSUPPORTED = -4
+};
+
+#define HC_MODEL_VRETTAS_FUNG 0
+#define HC_MODEL_VAN_GENUCHTEN 1
+#define HC_MAX_DEPTH_NODES 640 /* 64 lanes x 10 cells */
+
+/* One soil column geometry + parameter point (static during a run). */
+typedef struct {
+    int32_t dim_d;        /* D depth nodes (z_grid.size)                              */
+    int32_t model;        /* HC_MODEL_*                                               */
+    int32_t flag_et;      /* Simulation_Flags.ET                                      */
+    int32_t flag_lf;      /* Simulation_Flags.LF  (monitoring mode)                   */
+    int32_t flag_hlift;   /* Simulation_Flags.HLIFT                                   */
+    int32_t n_root_first; /* root-zone cells of the first-midpoint call (0 or 1)      */
+    int32_t n_root_int;   /* root-zone cells of the interior call                     */
+    int32_t n_groups;     /* FD-Jacobian column groups                                */
+    double theta_res, alpha, n, m, psi_sat, epsilon, lambda_exp, sigma_noise, sat_soil, dz;
+    double ipsi50, lai, surface_evap, interception, evap_delta_min;
+} hc_column_params;
+
+/* node_tabs: [3][D] rows = porosity, mean-K, noise coefficient (-1 = no layer) at the nodes
+ * mid_tabs : [6][D-1] rows = porosity, field capacity, wilting point, root pdf, mean-K,
+ *            noise coefficient at the midpoints
+ * groups   : [D] column group of every state entry (scipy group_columns for a tridiagonal) */
+int hc_create(int device_ordinal, hc_handle **out);
+int hc_destroy(hc_handle *h);
+const char *hc_last_error(void);
+const char *hc_version(void);
+
+int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_tabs,
+                  const double *mid_tabs, const int32_t *groups);
+
+/* Forcing struct-of-arrays, n_rows entries each; wtd_obs < 0 marks a row to skip
+ * (src/simulation.py:582-588); draw_idx[i] = index of the noise draw a refresh row uses
+ * (1-based count of refresh rows up to and including i; 0 = base vector). */
+int hc_set_forcing(hc_handle *h, int64_t n_rows, const double *precip, const double *atm,
+                   const uint8_t *daylight, const int32_t *wtd_obs, const uint8_t *refresh);
+
+int hc_set_members(hc_handle *h, int64_t n_members);
+/* psi: [n_members][D], or [D] when broadcast != 0 */
+int hc_set_state(hc_handle *h, const double *psi, int broadcast);
+int hc_get_state(hc_handle *h, double *psi, int64_t first_member, int64_t count);
+
+/* Noise source A (parity): host-supplied base vectors [n_members][D]; refresh-row vectors are
+ * passed to hc_step_rows.  Mutated in place by the x0.8 retry rule (src/richards_pde.py:522). */
+int hc_set_noise_host(hc_handle *h, const double *base);
+int hc_get_noise_base(hc_handle *h, double *base, int64_t first_member, int64_t count);
+/* Noise source B (throughput): counter-based Philox4x32-10 + Box-Muller generated in-kernel;
+ * stream = (seed, member_offset + member, draw index, depth).  The retry damping is kept as a
+ * per-member scale factor. */
+int hc_set_noise_philox(hc_handle *h, uint64_t seed, int64_t member_offset);
+/* What the Philox source yields for (member, draw): out[D] (test hook). */
+int hc_philox_normals(hc_handle *h, int64_t member, int64_t draw, double *out);
+
+typedef struct {
+    int64_t row_begin;      /* first row to solve (row i integrates t in [i-1, i]); >= 1      */
+    int64_t n_rows;
+    int32_t spinup;         /* 1: SPINUP semantics (src/simulation.py:398): row_begin is used as
+                               the forcing row for every solve, t_span = (0,1), noise never refreshed */
+    int32_t accumulate_moments; /* add (count, sum idx, sum idx^2) of wtd_est per row          */
+    const double *fresh_noise;  /* host-noise mode: [n_refresh_rows_in_range][n_members][D]    */
+    int32_t *wtd_out;       /* nullable: [n_rows][n_members] wtd_est index per row             */
+    int32_t *stats_out;     /* nullable: [n_rows][n_members][6] nfev,njev,nlu,nsteps,attempts,refresh */
+    double *psi_rows_out;   /* nullable: [n_rows][n_members][D] state after every row          */
+    double kernel_ms;       /* out: device time of the launch(es), HIP events on the stream    */
+    int64_t launches;       /* out */
+} hc_step_args;
+
+int hc_step_rows(hc_handle *h, hc_step_args *a);
+int hc_synchronize(hc_handle *h);
+
+/* moments: [3][n_forcing_rows] int64 = count, sum(idx), sum(idx^2) of wtd_est over members */
+int hc_get_moments(hc_handle *h, int64_t *moments);
+int hc_set_moments(hc_handle *h, const int64_t *moments);
+int hc_reset_moments(hc_handle *h);
+
+/* Test hooks -------------------------------------------------------------------------- */
+/* dydt for every member's current state on forcing row `row` (noise = base vectors).
+ * aux (nullable): [n_members][3*(D-1)+1] = c | s | f at the midpoints, then pL. */
+int hc_rhs(hc_handle *h, int64_t row, int32_t spinup, double *dydt, double *aux);
+/* plugin call on the nodes for every member's current state: out [4][n_members][D]
+ * = theta, K, C, K_bkg; qinf [n_members] (nullable) */
+int hc_model_nodes(hc_handle *h, double *out, double *qinf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
