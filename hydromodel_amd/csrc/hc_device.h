@@ -1,0 +1,443 @@
+// hc_device.h -- device-side building blocks of the gfx950 column stepper.
+//
+// Execution model: ONE 64-lane wavefront integrates ONE ensemble member.  Lane l owns the
+// CPL consecutive depth nodes [l*CPL, (l+1)*CPL) ("chunked" layout), so the 3-point stencil,
+// prefix sums and the tridiagonal solve are lane-local except at chunk edges, which move
+// through cross-lane shuffles.  Per-wave vectors live in registers (double v[CPL]) or in LDS
+// as v[c*64 + lane] (conflict-free for every CPL).
+//
+// Reference anchors (paths relative to /root/reference/code/src):
+//   model_cell      models/vrettas_fung.py:108-257, models/vanGenuchten.py:71-121, utilities.py:4-54
+//   rhs_eval        richards_pde.py:82-160 (__call__), :172-395 (pde_fun), :414-476 (bc_fun),
+//                   tree_roots.py:179-292 (efficiency), utilities.py:56-99 (find_wtd)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hc {
+
+constexpr int WAVE = 64;
+
+// slot tables staged in LDS, [NTAB][64*CPL] doubles
+enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, NTAB };
+// per-slot integer tables, [NGTAB][64*CPL]
+enum { G_SELF = 0, G_PREV, G_NEXT, NGTAB };
+
+struct ColumnDev {
+    int D, model, flag_et, flag_lf, flag_hlift, n_root_first, n_root_int, n_groups;
+    double theta_res, alpha, n, m, psi_sat, epsilon, lambda, sigma, sat_soil, dz, inv_dz;
+    double ipsi50, lai, surface_evap, interception, evap_delta_min;
+    double mn_alpha;    // (m*n)*alpha
+    double inv_m;       // 1/m
+    double por_node0;   // porosity the top-node BC call sees
+};
+
+struct RowDev {
+    double precip, atm;
+    int daylight, wtd_obs, spinup;
+};
+
+// ---------------------------------------------------------------- wave primitives
+__device__ __forceinline__ double readlane_d(double v, int lane /*uniform*/)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double uniform_d(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return uniform_d(v);
+}
+__device__ __forceinline__ void wave_sum2(double &a, double &b)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double ta = __shfl_xor(a, o, WAVE), tb = __shfl_xor(b, o, WAVE);
+        a += ta;
+        b += tb;
+    }
+    a = uniform_d(a);
+    b = uniform_d(b);
+}
+// exclusive prefix sum across lanes
+__device__ __forceinline__ double wave_excl_scan(double v, int lane)
+{
+    double incl = v;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        double t = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += t;
+    }
+    double ex = __shfl_up(incl, 1, WAVE);
+    return lane == 0 ? 0.0 : ex;
+}
+__device__ __forceinline__ double shfl_up1(double v, int lane, double fill)
+{
+    double t = __shfl_up(v, 1, WAVE);
+    return lane == 0 ? fill : t;
+}
+__device__ __forceinline__ double shfl_down1(double v, int lane, double fill)
+{
+    double t = __shfl_down(v, 1, WAVE);
+    return lane == WAVE - 1 ? fill : t;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// standard normal for (seed, member, draw, depth index i)
+__device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t member, uint32_t draw, uint32_t i)
+{
+    uint32_t r[4];
+    philox4x32_10(i >> 1, draw, (uint32_t)member, (uint32_t)(member >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    uint64_t a = ((uint64_t)r[1] << 32) | r[0], b = ((uint64_t)r[3] << 32) | r[2];
+    double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    return (i & 1) ? rad * s : rad * c;
+}
+
+// ---------------------------------------------------------------- the plugin, one cell
+// SPECIAL: vrettas_fung with n = 2, m = 1/2, lambda = 1 (the reference's input_parameters.json);
+// pow() disappears.  Generic path keeps pow() and the model switch.
+template <bool SPECIAL>
+__device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, double por, double logm,
+                                           double invm2, double noisec, double rnd, double &theta,
+                                           double &K, double &C, double &kb, double &pfac)
+{
+    const double delta = por - P.theta_res;
+    const bool sat = psi >= P.psi_sat;
+    const double ap = P.alpha * fabs(psi);
+    if (SPECIAL)
+        pfac = rsqrt(1.0 + ap * ap);
+    else
+        pfac = pow(1.0 + pow(ap, P.n), -P.m);
+    double q = P.theta_res + delta * pfac;
+    q = sat ? por : q;
+    double s = (q - P.theta_res) / delta;
+    {   // np.minimum(np.maximum(s, 0), 1): NaN propagates
+        double sc = fmin(fmax(s, 0.0), 1.0);
+        s = (s != s) ? s : sc;
+    }
+    if (SPECIAL || P.model == 0) {
+        // K_bkg = exp(log(m^2/sqrt(v+m^2)) + sqrt(log(v/m^2+1))*rnd)  ==  exp(log m - Lt/2 + sqrt(Lt)*rnd),
+        // Lt = log(v/m^2 + 1)   (utilities.py:10-19 restructured: one log, one sqrt, one exp)
+        const double var = P.sigma * (1.0 - s);
+        const double t = var * invm2 + 1.0;
+        const double Lt = log(t);
+        const double sig = sqrt(Lt);
+        kb = exp(logm - 0.5 * Lt + sig * rnd);
+        kb = noisec < 0.0 ? P.sat_soil : kb;   // cell in no layer: vrettas_fung.py:143
+        const double sl = SPECIAL ? s : pow(s, P.lambda);
+        K = sl * kb;
+    } else {
+        // vanGenuchten.py:91-98
+        kb = P.sat_soil;
+        const double mth = pow(s, P.inv_m);
+        K = kb * sqrt(s) * pow(1.0 - pow(1.0 - mth, P.m), P.n);
+    }
+    K = sat ? kb : K;
+    K = (K != K) ? K : fmin(K, kb);
+    double s3, apn;
+    if (SPECIAL) {
+        s3 = s * s * s;
+        apn = ap;
+    } else {
+        s3 = pow(s, P.inv_m + 1.0);
+        apn = pow(ap, P.n - 1.0);
+    }
+    double c = P.mn_alpha * delta * s3 * apn;
+    c = sat ? P.epsilon : c;
+    c = (c < P.epsilon || !isfinite(c)) ? P.epsilon : c;
+    theta = q;
+    C = c;
+}
+
+// deepest cell index with pred true, or -1: cells are (lane, c) -> index lane*CPL + c
+template <int CPL>
+__device__ __forceinline__ int deepest_true(const bool (&pred)[CPL])
+{
+    int best = -1;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        unsigned long long m = __ballot(pred[c]);
+        if (m) {
+            int hi = 63 - __clzll((long long)m);
+            int cand = hi * CPL + c;
+            best = cand > best ? cand : best;
+        }
+    }
+    return uniform_i(best);
+}
+
+// ---------------------------------------------------------------- RHS of the method of lines
+// y[c]   : state at node lane*CPL + c
+// rnd[c] : scaled noise of the cell evaluated in slot c (midpoint lane*CPL+c; the virtual top-node
+//          cell sits in the always-free slot (lane 63, c = CPL-1))
+// f[c]   : dy/dt at node lane*CPL + c (0 beyond the grid)
+// aux    : optional global pointer [3*(D-1)+1] receiving c | s | f at the midpoints and pL
+template <int CPL, bool SPECIAL>
+__device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, const double *tab,
+                                         int lane, const double (&y)[CPL], const double (&rnd)[CPL],
+                                         double (&f)[CPL], double *aux)
+{
+    constexpr int SLOTS = WAVE * CPL;
+    const int D = P.D;
+    const double half = 0.5 * P.dz;
+    double ym[CPL], dym[CPL], th[CPL], Kc[CPL], Cc[CPL], fl[CPL], sk[CPL];
+    const double y_top = readlane_d(y[0], 0);
+    const double y_nf = shfl_down1(y[0], lane, 0.0);
+    double kb_top = 0.0, th_top = 0.0, pf_top = 0.0;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = lane * CPL + c;
+        const double yn = (c + 1 < CPL) ? y[c + 1 < CPL ? c + 1 : c] : y_nf;
+        const bool vmid = i < D - 1;
+        const bool vtop = (c == CPL - 1) && (lane == WAVE - 1);
+        double psi = 0.5 * (y[c] + yn);
+        double dy = (yn - y[c]) * P.inv_dz;
+        psi = vmid ? psi : (vtop ? y_top : -100.0);
+        dy = vmid ? dy : 0.0;
+        ym[c] = psi;
+        dym[c] = dy;
+        const int slot = c * WAVE + lane;
+        double kb, pf;
+        model_cell<SPECIAL>(P, psi, tab[T_POR * SLOTS + slot], tab[T_LOGM * SLOTS + slot],
+                            tab[T_INVM2 * SLOTS + slot], tab[T_NOISEC * SLOTS + slot], rnd[c], th[c],
+                            Kc[c], Cc[c], kb, pf);
+        fl[c] = Kc[c] * (dy - 1.0);
+        sk[c] = 0.0;
+        if (c == CPL - 1) {
+            kb_top = kb;
+            th_top = th[c];
+            pf_top = pf;
+        }
+    }
+    const bool normal_mode = !R.spinup;
+    // ---- hydraulic lift (night only), richards_pde.py:234-254
+    if (P.flag_hlift && normal_mode && !R.daylight) {
+        const double c_sat = 1800.0 * P.lai;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int i = lane * CPL + c;
+            const bool isr = (i == 0) ? (P.n_root_first > 0) : (i <= P.n_root_int);
+            const double t1 = 1.0 - P.ipsi50 * ym[c];
+            const double c_hr = c_sat * (t1 * t1) * tab[T_ROOT * SLOTS + c * WAVE + lane];
+            const double add = 0.5 * c_hr * (dym[c] * P.dz);
+            fl[c] += (isr && i < D - 1) ? add : 0.0;
+        }
+    }
+    // ---- evapo-transpiration (daylight only), richards_pde.py:258-302 + tree_roots.py:213-291
+    if (P.flag_et && normal_mode && R.daylight) {
+        // (a) interior call: midpoints 1..n_root_int, normalised together
+        if (P.n_root_int > 0) {
+            bool isr[CPL];
+            double wl[CPL], fcv[CPL], pre[CPL];
+            double s_w = 0.0, s_t = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int i = lane * CPL + c;
+                isr[c] = (i >= 1) && (i <= P.n_root_int);
+                wl[c] = tab[T_WLT * SLOTS + c * WAVE + lane];
+                fcv[c] = tab[T_FC * SLOTS + c * WAVE + lane];
+                s_w += isr[c] ? th[c] - wl[c] : 0.0;
+                s_t += isr[c] ? th[c] : 0.0;
+                pre[c] = s_t;
+            }
+            const double lane_tot = s_t;
+            double tot_theta = s_t;
+            wave_sum2(s_w, tot_theta);
+            double water_k = s_w * P.dz;
+            double x_out[CPL];
+            if (water_k > 0.0) {
+                const double excl = wave_excl_scan(lane_tot, lane);
+                double total = tot_theta * P.dz;
+                total = total == 0.0 ? 1.0 : total;
+                double a2[CPL];
+                bool all_one = true;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    double v = 0.0;
+                    if (wl[c] < th[c] && th[c] <= fcv[c]) {
+                        double d2 = fcv[c] - wl[c];
+                        d2 = d2 == 0.0 ? 1.0 : d2;
+                        v = (th[c] - fcv[c]) / d2;
+                    }
+                    v = th[c] > fcv[c] ? 1.0 : v;
+                    v = fmin(fmax(v, 0.0), 1.0);
+                    a2[c] = v;
+                    all_one = all_one && (!isr[c] || v == 1.0);
+                }
+                const bool wave_all_one = __all(all_one);
+                double s_r = 0.0;
+                double rho[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    double d1 = tab[T_POR * SLOTS + c * WAVE + lane] - wl[c];
+                    d1 = d1 == 0.0 ? 1.0 : d1;
+                    const double local = (excl + pre[c]) * P.dz;
+                    const double a1 = fmax(th[c] / d1, local / total);
+                    const double v = wave_all_one ? a2[c] * 0.1 : a2[c];
+                    rho[c] = isr[c] ? fabs(a1 * v) : 0.0;
+                    s_r += rho[c];
+                }
+                double tot = wave_sum(s_r) * P.dz;
+                tot = tot == 0.0 ? 1.0 : tot;
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                    x_out[c] = (rho[c] / tot) * tab[T_ROOT * SLOTS + c * WAVE + lane];
+            } else {
+                water_k = 0.0;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) x_out[c] = 0.0;
+            }
+            double s_x = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) s_x += isr[c] ? x_out[c] : 0.0;
+            double tot_x = wave_sum(s_x) * P.dz;
+            if (tot_x > 1.0) {
+                s_x = 0.0;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    x_out[c] = x_out[c] / tot_x;
+                    s_x += isr[c] ? x_out[c] : 0.0;
+                }
+                tot_x = wave_sum(s_x) * P.dz;
+            }
+            if (tot_x > 0.0) {
+                const double tr_pot = fmin(R.atm, water_k) / tot_x;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) sk[c] = isr[c] ? -(tr_pot * x_out[c]) : sk[c];
+            }
+        }
+        // (b) first-midpoint call: one cell normalised on its own
+        if (P.n_root_first > 0 && lane == 0) {
+            const double t0 = th[0], w0 = tab[T_WLT * SLOTS + lane], f0 = tab[T_FC * SLOTS + lane];
+            double water_k = (t0 - w0) * P.dz;
+            double x0 = 0.0;
+            if (water_k > 0.0) {
+                const double local = t0 * P.dz;
+                const double total = local == 0.0 ? 1.0 : local;
+                double d1 = tab[T_POR * SLOTS + lane] - w0;
+                d1 = d1 == 0.0 ? 1.0 : d1;
+                const double a1 = fmax(t0 / d1, local / total);
+                double v = 0.0;
+                if (w0 < t0 && t0 <= f0) {
+                    double d2 = f0 - w0;
+                    d2 = d2 == 0.0 ? 1.0 : d2;
+                    v = (t0 - f0) / d2;
+                }
+                v = t0 > f0 ? 1.0 : v;
+                v = fmin(fmax(v, 0.0), 1.0);
+                v = v == 1.0 ? v * 0.1 : v;
+                double rho = fabs(a1 * v);
+                double tot = rho * P.dz;
+                tot = tot == 0.0 ? 1.0 : tot;
+                x0 = (rho / tot) * tab[T_ROOT * SLOTS + lane];
+            } else {
+                water_k = 0.0;
+            }
+            double tot_x = x0 * P.dz;
+            if (tot_x > 1.0) {
+                x0 = x0 / tot_x;
+                tot_x = x0 * P.dz;
+            }
+            if (tot_x > 0.0) sk[0] = -((fmin(R.atm, water_k) / tot_x) * x0);
+        }
+    }
+    // ---- lateral flow, monitoring mode, richards_pde.py:352-376 (interior slice only; the
+    //      single-cell first call can never satisfy wtd_est < wtd_obs)
+    if (P.flag_lf) {
+        const int k = D - 2;
+        bool unsat[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int i = lane * CPL + c;
+            unsat[c] = (i >= 1) && (i <= D - 2) && !(ym[c] >= P.psi_sat);
+        }
+        const int jstar = deepest_true<CPL>(unsat);          // midpoint index, local position p = j-1
+        int wtd_est = jstar < 0 ? 0 : jstar;                  // p* + 1
+        wtd_est = wtd_est < k - 1 ? wtd_est : k - 1;
+        const int wtd_obs = R.wtd_obs < k - 1 ? R.wtd_obs : k - 1;
+        if (wtd_est < wtd_obs) {
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int p = lane * CPL + c - 1;
+                const bool in = (p >= wtd_est) && (p < wtd_obs);
+                sk[c] = in ? fmin(-2.5e-4 * ym[c], sk[c]) : sk[c];
+            }
+        }
+    }
+    // ---- top boundary, richards_pde.py:414-476 (computed in lane 63's spare slot)
+    double pL;
+    {
+        const double qinf = fmin(2.0 * (P.por_node0 - th_top) * P.dz, kb_top);
+        const double net = (1.0 - P.interception) * fabs(R.precip);
+        double p = (y_top < P.psi_sat) ? fmin(net, qinf) : 0.0;
+        if (normal_mode) {
+            const double q_min = P.theta_res + P.evap_delta_min * pf_top;
+            const bool allow = (th_top > P.theta_res) && (q_min > P.theta_res);
+            p = (allow && R.daylight) ? p - P.surface_evap : p;
+        }
+        pL = readlane_d(p, WAVE - 1);
+    }
+    // ---- assemble dy/dt, richards_pde.py:108-156
+    const double cP0 = shfl_up1(Cc[CPL - 1], lane, 0.0);
+    const double sP0 = shfl_up1(sk[CPL - 1], lane, 0.0);
+    const double fP0 = shfl_up1(fl[CPL - 1], lane, 0.0);
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = lane * CPL + c;
+        const double cP = c == 0 ? cP0 : Cc[c > 0 ? c - 1 : 0];
+        const double sP = c == 0 ? sP0 : sk[c > 0 ? c - 1 : 0];
+        const double fP = c == 0 ? fP0 : fl[c > 0 ? c - 1 : 0];
+        double num, den;
+        if (i == 0) {
+            den = half * Cc[c];
+            num = pL + (fl[c] + half * sk[c]);
+        } else if (i < D - 1) {
+            den = half * Cc[c] + half * cP;
+            num = fl[c] - fP + (half * sk[c] + half * sP);
+        } else {
+            den = -half * cP;
+            num = fP - half * sP;
+        }
+        den = den == 0.0 ? 1.0 : den;
+        f[c] = i < D ? num / den : 0.0;
+        if (aux && i < D - 1) {
+            aux[i] = Cc[c];
+            aux[(D - 1) + i] = sk[c];
+            aux[2 * (D - 1) + i] = fl[c];
+        }
+    }
+    if (aux && lane == 0) aux[3 * (D - 1)] = pL;
+}
+
+}  // namespace hc

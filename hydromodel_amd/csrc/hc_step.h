@@ -1,0 +1,750 @@
+// hc_step.h -- the fused column-step kernel: rows x (<=5 attempts) x variable-order BDF.
+//
+// Restates, per wavefront = per ensemble member:
+//   Simulation.run row loop            /root/reference/code/src/simulation.py:576-626
+//   RichardsPDE.solve (5 attempts)     /root/reference/code/src/richards_pde.py:478-537
+//   scipy solve_ivp(method='BDF')      scipy/integrate/_ivp/bdf.py (BDF.__init__, _step_impl,
+//                                      solve_bdf_system, change_D), common.py (select_initial_step,
+//                                      norm, num_jac/_sparse_num_jac) -- third-party, restated
+//
+// Structure: a single loop with ONE inlined RHS site; a wave-uniform phase variable says who
+// consumes the RHS value (initial slope, step-size probe, FD-Jacobian column group, Newton
+// iterate).  All step-control decisions are wave-uniform scalars.  The linear solves with
+// I - c*J use a lane-partitioned (Wang) tridiagonal factorisation: lane-local elimination,
+// a 64-unknown reduced system solved by parallel cyclic reduction through shuffles, lane-local
+// back substitution.
+#pragma once
+#include "hc_device.h"
+
+namespace hc {
+
+constexpr double EPS = 2.220446049250313e-16;
+constexpr double SQRT_EPS = 1.4901161193847656e-08;
+constexpr double RTOL = 1.0e-3, ATOL = 1.0e-3;          // richards_pde.py:496
+constexpr double NEWTON_TOL = 0.03;                      // max(10*EPS/rtol, min(0.03, sqrt(rtol)))
+constexpr int NEWTON_MAXITER = 4;
+constexpr int MAX_ORDER = 5;
+constexpr double NUM_JAC_DIFF_REJECT = 2.0097183471152322e-14;
+constexpr double NUM_JAC_DIFF_SMALL = 1.8189894035458565e-12;
+constexpr double NUM_JAC_DIFF_BIG = 0.0001220703125;
+constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
+
+// per-wave LDS vectors (each 64*CPL doubles)
+enum { V_Y = 0, V_FP, V_NZ, V_FAC, V_D0, NVEC = V_D0 + MAX_ORDER + 3 };
+constexpr int WAVE_SCRATCH = 128;   // doubles: RU matrices (3 x 36) + row-0 values of the FD groups
+
+struct StepArgs {
+    ColumnDev P;
+    const double *tab;        // [NTAB][SLOTS]
+    const int *gtab;          // [NGTAB][SLOTS]
+    double *psi;              // [N][D] in/out
+    double *base_noise;       // [N][D] or null (Philox)
+    const double *fresh;      // [n_fresh][N][D] or null
+    double *nscale;           // [N] Philox-mode damping factor of the base vector
+    const double *precip, *atm;
+    const unsigned char *daylight, *refresh;
+    const int *wtd_obs, *draw_idx;
+    long long n_members, member_offset;
+    long long row_begin;
+    int n_rows, spinup;
+    unsigned long long seed;
+    unsigned short *wtd_u16;  // [n_rows][N]
+    int *stats;               // [n_rows][N][6] or null
+    double *psi_rows;         // [n_rows][N][D] or null
+    unsigned long long *counters;   // [0] FD-Jacobian redo events (unsupported path), [1] failed attempts
+};
+
+// gamma = [0, cumsum(1/k)], alpha = (1 - kappa) * gamma, error_const = kappa * gamma + 1/(k+1)
+// with kappa = [0, -0.1850, -1/9, -0.0823, -0.0415, 0]  (bdf.py BDF.__init__), as NumPy evaluates them
+__device__ const double GAMMA_TAB[6] = {0.0, 1.0, 1.5, 1.8333333333333333, 2.083333333333333, 2.283333333333333};
+__device__ const double ALPHA_TAB[6] = {0.0, 1.185, 1.6666666666666667, 1.9842166666666667, 2.1697916666666663, 2.283333333333333};
+__device__ const double ERRC_TAB[6] = {1.0, 0.315, 0.16666666666666666, 0.09911666666666669, 0.11354166666666668, 0.16666666666666666};
+__device__ __forceinline__ double gamma_k(int k) { return GAMMA_TAB[k]; }
+__device__ __forceinline__ double alpha_k(int k) { return ALPHA_TAB[k]; }
+__device__ __forceinline__ double error_const_k(int k) { return ERRC_TAB[k]; }
+
+// RMS norm of x[c]/s[c] over the D valid nodes
+template <int CPL>
+__device__ __forceinline__ double rms_ratio(const double (&x)[CPL], const double (&s)[CPL], int lane, int D,
+                                            double inv_sqrt_d)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const double r = x[c] / s[c];
+        acc += (lane * CPL + c < D) ? r * r : 0.0;
+    }
+    return sqrt(wave_sum(acc)) * inv_sqrt_d;
+}
+
+// bdf.py change_D: D[:order+1] = (R(order,factor) @ R(order,1)).T @ D[:order+1]
+template <int CPL>
+__device__ __forceinline__ void change_D(double *Dv, double *ru, int order, double factor, int lane)
+{
+    constexpr int SLOTS = WAVE * CPL;
+    const int i = lane / 6, j = lane % 6;
+    double r = 1.0, u = 1.0;
+    if (lane < 36) {
+        if (i >= 1) {
+            if (j == 0) {
+                r = 0.0;
+                u = 0.0;
+            } else {
+                for (int q = 1; q <= i; q++) {
+                    r *= ((double)(q - 1) - factor * (double)j) / (double)q;
+                    u *= ((double)(q - 1) - (double)j) / (double)q;
+                }
+            }
+        }
+        ru[lane] = r;
+        ru[36 + lane] = u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+        double s = 0.0;
+        for (int k = 0; k <= order; k++) s += ru[i * 6 + k] * ru[36 + k * 6 + j];
+        ru[72 + lane] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double m[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) m[a][b] = (a <= order && b <= order) ? ru[72 + a * 6 + b] : 0.0;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int slot = c * WAVE + lane;
+        double col[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) col[k] = k <= order ? Dv[k * SLOTS + slot] : 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            if (a <= order) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s += m[k][a] * col[k];
+                Dv[a * SLOTS + slot] = s;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- lane-partitioned tridiagonal factorisation of A = I - cc*J -------------------------
+template <int CPL>
+struct TriLU {
+    double wf[CPL], wb[CPL], l[CPL], u[CPL], ib[CPL];
+    double wx, invB, al[6], ga[6];
+};
+
+template <int CPL>
+__device__ __forceinline__ void lu_factor(TriLU<CPL> &F, const double (&jl)[CPL], const double (&jd)[CPL],
+                                          const double (&ju)[CPL], double cc, int lane, int D)
+{
+    double a[CPL], b[CPL], cu[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const bool v = lane * CPL + c < D;
+        a[c] = v ? -cc * jl[c] : 0.0;
+        b[c] = v ? 1.0 - cc * jd[c] : 1.0;
+        cu[c] = v ? -cc * ju[c] : 0.0;
+    }
+    // forward: remove the sub-diagonal inside the chunk; fill-in l[] couples to x_{s-1}
+    F.l[0] = a[0];
+    F.wf[0] = 0.0;
+#pragma unroll
+    for (int c = 1; c < CPL; c++) {
+        const double w = a[c] / b[c - 1];
+        F.wf[c] = w;
+        F.l[c] = -w * F.l[c - 1];
+        b[c] -= w * cu[c - 1];
+    }
+    // backward: remove the super-diagonal of rows s..e-2; fill-in u[] couples to x_e
+    F.u[CPL - 1] = cu[CPL - 1];   // row e: still coupled to the next chunk's first unknown
+    F.wb[CPL - 1] = 0.0;
+    if (CPL >= 2) {
+        F.u[CPL - 2] = cu[CPL - 2];
+        F.wb[CPL - 2] = 0.0;
+    }
+#pragma unroll
+    for (int c = CPL - 3; c >= 0; c--) {
+        const double w = cu[c] / b[c + 1];
+        F.wb[c] = w;
+        F.l[c] -= w * F.l[c + 1];
+        F.u[c] = -w * F.u[c + 1];
+    }
+    // last row of the chunk: eliminate x_{s'} with the next lane's first row (l,b,u)
+    const double nl = shfl_down1(F.l[0], lane, 0.0);
+    const double nb = shfl_down1(b[0], lane, 1.0);
+    const double nu = shfl_down1(F.u[0], lane, 0.0);
+    const double w = F.u[CPL - 1] / nb;
+    F.wx = w;
+    double L = F.l[CPL - 1], B = b[CPL - 1] - w * nl, U = -w * nu;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) F.ib[c] = 1.0 / b[c];
+    // parallel cyclic reduction on the 64 chunk-end unknowns
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        const int d = 1 << s;
+        double Bm = __shfl_up(B, d, WAVE), Um = __shfl_up(U, d, WAVE), Lm = __shfl_up(L, d, WAVE);
+        double Bp = __shfl_down(B, d, WAVE), Lp = __shfl_down(L, d, WAVE), Up = __shfl_down(U, d, WAVE);
+        const bool hm = lane >= d, hp = lane + d < WAVE;
+        Bm = hm ? Bm : 1.0; Um = hm ? Um : 0.0; Lm = hm ? Lm : 0.0;
+        Bp = hp ? Bp : 1.0; Lp = hp ? Lp : 0.0; Up = hp ? Up : 0.0;
+        const double al = -L / Bm, ga = -U / Bp;
+        F.al[s] = al;
+        F.ga[s] = ga;
+        B = B + al * Um + ga * Lp;
+        L = al * Lm;
+        U = ga * Up;
+    }
+    F.invB = 1.0 / B;
+}
+
+template <int CPL>
+__device__ __forceinline__ void lu_solve(const TriLU<CPL> &F, double (&x)[CPL], int lane)
+{
+#pragma unroll
+    for (int c = 1; c < CPL; c++) x[c] -= F.wf[c] * x[c - 1];
+#pragma unroll
+    for (int c = CPL - 3; c >= 0; c--) x[c] -= F.wb[c] * x[c + 1];
+    const double nd = shfl_down1(x[0], lane, 0.0);
+    double Rr = x[CPL - 1] - F.wx * nd;
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        const int d = 1 << s;
+        double Rm = __shfl_up(Rr, d, WAVE), Rp = __shfl_down(Rr, d, WAVE);
+        Rm = lane >= d ? Rm : 0.0;
+        Rp = lane + d < WAVE ? Rp : 0.0;
+        Rr = Rr + F.al[s] * Rm + F.ga[s] * Rp;
+    }
+    const double xe = Rr * F.invB;
+    const double xp = shfl_up1(xe, lane, 0.0);
+    x[CPL - 1] = xe;
+#pragma unroll
+    for (int c = 0; c < CPL - 1; c++) x[c] = (x[c] - F.l[c] * xp - F.u[c] * xe) * F.ib[c];
+}
+
+enum Phase {
+    PH_F0 = 0, PH_F1, PH_JAC, PH_NEWTON,
+    C_JAC_FIN, C_STEP_BEGIN, C_STEP_TRY, C_NEWTON_BEGIN, C_NEWTON_FAIL, C_ERR_TEST, C_ACCEPT,
+    C_SUCCESS, C_FAIL
+};
+
+template <int CPL, bool SPECIAL, int WPB>
+__global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
+{
+    constexpr int SLOTS = WAVE * CPL;
+    extern __shared__ double lds[];
+    double *tab = lds;
+    int *gtab = reinterpret_cast<int *>(tab + NTAB * SLOTS);
+    double *wave_base = reinterpret_cast<double *>(gtab + 4 * SLOTS);
+    for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
+    for (int k = threadIdx.x; k < NGTAB * SLOTS; k += WPB * WAVE) gtab[k] = A.gtab[k];
+    __syncthreads();
+
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const long long member = (long long)blockIdx.x * WPB + wave;
+    if (member >= A.n_members) return;          // no barrier below this line
+    double *V = wave_base + (size_t)wave * (NVEC * SLOTS + WAVE_SCRATCH);
+    double *ru = V + NVEC * SLOTS;
+    double *row0 = ru + 108;                    // f_new[group][row 0], <= 16 groups
+    double *Dv = V + V_D0 * SLOTS;
+    const ColumnDev &P = A.P;
+    const int D = P.D;
+    const double inv_sqrt_d = 1.0 / sqrt((double)D);
+
+    bool vnode[CPL];
+    int gs[CPL], gp[CPL], gn[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        vnode[c] = lane * CPL + c < D;
+        gs[c] = gtab[G_SELF * SLOTS + c * WAVE + lane];
+        gp[c] = gtab[G_PREV * SLOTS + c * WAVE + lane];
+        gn[c] = gtab[G_NEXT * SLOTS + c * WAVE + lane];
+    }
+    // state -> LDS
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+        V[V_Y * SLOTS + c * WAVE + lane] = vnode[c] ? A.psi[member * D + lane * CPL + c] : 0.0;
+
+    double nscale = A.base_noise ? 1.0 : A.nscale[member];
+    int fresh_seen = 0;
+
+    for (int r = 0; r < A.n_rows; r++) {
+        const long long row = A.spinup ? A.row_begin : A.row_begin + r;
+        RowDev R;
+        R.precip = A.precip[row];
+        R.atm = A.atm[row];
+        R.daylight = A.daylight[row];
+        R.wtd_obs = A.wtd_obs[row];
+        R.spinup = A.spinup;
+        const bool refresh = !A.spinup && A.refresh[row];
+        const double t0 = A.spinup ? 0.0 : (double)(row - 1);
+        const double tf = t0 + 1.0;
+        int st_nfev = 0, st_njev = 0, st_nlu = 0, st_nsteps = 0, attempts = 0;
+        bool skip = (R.wtd_obs < 0) && !A.spinup;    // simulation.py:582-588
+        if (!skip) {
+            // ---- noise vector of this row -> V_NZ (simulation.py:592,599-602)
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int i = lane * CPL + c;
+                double z = 0.0;
+                if (vnode[c]) {
+                    if (A.base_noise) {
+                        z = refresh ? A.fresh[((size_t)fresh_seen * A.n_members + member) * D + i]
+                                    : A.base_noise[member * D + i];
+                    } else {
+                        const unsigned draw = refresh ? (unsigned)A.draw_idx[row] : 0u;
+                        z = philox_normal(A.seed, (unsigned long long)(A.member_offset + member), draw, (unsigned)i);
+                        z = refresh ? z : z * nscale;
+                    }
+                }
+                V[V_NZ * SLOTS + c * WAVE + lane] = z;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int failed = 0;
+            double yrow0[CPL];                   // every attempt restarts from the row's y0
+#pragma unroll
+            for (int c = 0; c < CPL; c++) yrow0[c] = V[V_Y * SLOTS + c * WAVE + lane];
+            // ---- up to 5 attempts (richards_pde.py:509-533)
+            for (;;) {
+                attempts++;
+                // scaled noise per evaluated cell: midpoint j uses n_rnd[max(j-1,0)]; the virtual
+                // top-node cell (lane 63, last slot) uses n_rnd[0]   
+                double rnd[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    const int i = lane * CPL + c;
+                    int idx = i >= 1 ? i - 1 : 0;
+                    idx = (i < D - 1) ? idx : 0;
+                    const double z = V[V_NZ * SLOTS + (idx % CPL) * WAVE + idx / CPL];
+                    rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * z;
+                }
+                // ================= one BDF integration over [t0, tf] =================
+                double ycur[CPL], f[CPL], yp[CPL], psiv[CPL], scl[CPL], dd[CPL];
+                double jl[CPL], jd[CPL], ju[CPL], hj[CPL];
+                TriLU<CPL> F;
+                double t = t0, h_abs = 0.0, h0 = 0.0, t_new = t0, cc = 0.0, min_step = 0.0;
+                double dy_norm_old = -1.0, safety = 0.0, error_norm = 0.0;
+                int order = 1, n_equal = 0, have_lu = 0, current_jac = 0, newton_k = 0, n_iter = 0;
+                int g = 0, jac_init = 1, nfev = 0, njev = 0, nlu = 0, nsteps = 0, ok = 0;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    ycur[c] = yrow0[c];
+                    V[V_Y * SLOTS + c * WAVE + lane] = yrow0[c];   // sol.y[:, -1] before any accepted step
+                    Dv[0 * SLOTS + c * WAVE + lane] = ycur[c];
+                    V[V_FAC * SLOTS + c * WAVE + lane] = SQRT_EPS;
+                    yp[c] = psiv[c] = dd[c] = jl[c] = jd[c] = ju[c] = hj[c] = 0.0;
+                    scl[c] = 1.0;
+                }
+                int phase = PH_F0;
+                bool need_rhs = true;
+                for (;;) {
+                    if (need_rhs) rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr);
+                    need_rhs = true;
+                    if (phase == PH_F0) {
+                        // BDF.__init__: f0 = fun(t0, y0); select_initial_step part 1
+                        nfev++;
+                        double y0v[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            const int slot = c * WAVE + lane;
+                            y0v[c] = ycur[c];
+                            Dv[1 * SLOTS + slot] = f[c];      // parked here until h_abs is known
+                            V[V_FP * SLOTS + slot] = f[c];    // base f of the first Jacobian
+                            scl[c] = ATOL + fabs(y0v[c]) * RTOL;
+                        }
+                        const double d0 = rms_ratio<CPL>(y0v, scl, lane, D, inv_sqrt_d);
+                        const double d1 = rms_ratio<CPL>(f, scl, lane, D, inv_sqrt_d);
+                        h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                        h0 = fmin(h0, fabs(tf - t0));
+                        cc = d1;                              // carried to PH_F1
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            yp[c] = y0v[c];                   // Jacobian base point
+                            ycur[c] = y0v[c] + h0 * f[c];
+                        }
+                        phase = PH_F1;
+                    } else if (phase == PH_F1) {
+                        // select_initial_step part 2 (order = 1)
+                        nfev++;
+                        double df[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) df[c] = f[c] - V[V_FP * SLOTS + c * WAVE + lane];
+                        const double d1 = cc;
+                        const double d2 = rms_ratio<CPL>(df, scl, lane, D, inv_sqrt_d) / h0;
+                        double h1;
+                        if (d1 <= 1e-15 && d2 <= 1e-15)
+                            h1 = fmax(1e-6, h0 * 1e-3);
+                        else
+                            h1 = sqrt(0.01 / fmax(d1, d2));
+                        h_abs = fmin(fmin(100.0 * h0, h1), fabs(tf - t0));
+                        // first Jacobian: num_jac at (t0, y0) with f0 (the reference re-evaluates f0; same value)
+                        njev++;
+                        jac_init = 1;
+                        g = -1;
+                        phase = PH_JAC;
+                        need_rhs = false;
+                    } else if (phase == PH_JAC) {
+                        if (g < 0) {
+                            // common.num_jac: step h per column from factor, f sign and |y|
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                const int slot = c * WAVE + lane;
+                                const double fb = V[V_FP * SLOTS + slot];
+                                double fac = V[V_FAC * SLOTS + slot];
+                                const double ysc = (fb >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
+                                double h = (yp[c] + fac * ysc) - yp[c];
+                                while (vnode[c] && h == 0.0) {
+                                    fac *= 10.0;
+                                    h = (yp[c] + fac * ysc) - yp[c];
+                                }
+                                V[V_FAC * SLOTS + slot] = fac;
+                                hj[c] = vnode[c] ? h : 1.0;
+                            }
+                            g = 0;
+                        } else {
+                            // f holds fun(y + h * [group == g]); scatter into the three per-row slots
+                            const double r0v = readlane_d(f[0], 0);
+                            if (lane == 0) row0[g] = r0v;
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                jl[c] = (gp[c] == g) ? f[c] : jl[c];
+                                jd[c] = (gs[c] == g) ? f[c] : jd[c];
+                                ju[c] = (gn[c] == g) ? f[c] : ju[c];
+                            }
+                            g++;
+                        }
+                        if (g < P.n_groups) {
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) ycur[c] = yp[c] + ((gs[c] == g) ? hj[c] : 0.0);
+                        } else {
+                            phase = C_JAC_FIN;
+                            need_rhs = false;
+                        }
+                    } else if (phase == C_JAC_FIN) {
+                        // _sparse_num_jac: per-column max |diff| (rows j-1, j, j+1), its scale, factor update
+                        __builtin_amdgcn_wave_barrier();
+                        double fb[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) fb[c] = V[V_FP * SLOTS + c * WAVE + lane];
+                        const double fbU0 = shfl_up1(fb[CPL - 1], lane, 0.0), fnU0 = shfl_up1(ju[CPL - 1], lane, 0.0);
+                        const double fbD0 = shfl_down1(fb[0], lane, 0.0), fnD0 = shfl_down1(jl[0], lane, 0.0);
+                        const double hU0 = shfl_up1(hj[CPL - 1], lane, 1.0), hD0 = shfl_down1(hj[0], lane, 1.0);
+                        const double fb_row0 = readlane_d(fb[0], 0);
+                        bool small_any = false;
+                        double njl[CPL], njd[CPL], nju[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            const int i = lane * CPL + c;
+                            const double fbU = c == 0 ? fbU0 : fb[c > 0 ? c - 1 : 0];
+                            const double fnU = c == 0 ? fnU0 : ju[c > 0 ? c - 1 : 0];
+                            const double fbD = c == CPL - 1 ? fbD0 : fb[c < CPL - 1 ? c + 1 : c];
+                            const double fnD = c == CPL - 1 ? fnD0 : jl[c < CPL - 1 ? c + 1 : c];
+                            const bool hasU = i >= 1, hasD = i < D - 1;
+                            const double dU = hasU ? fabs(fnU - fbU) : -1.0;
+                            const double dM = fabs(jd[c] - fb[c]);
+                            const double dD = hasD ? fabs(fnD - fbD) : -1.0;
+                            // first maximum in row order j-1, j, j+1
+                            double md = dU, sf = fbU, sn = fnU;
+                            if (!(dU >= dM)) { md = dM; sf = fb[c]; sn = jd[c]; }
+                            if (hasD && dD > md) { md = dD; sf = fbD; sn = fnD; }
+                            if (!(md > 0.0)) {   // all-zero column: scipy's sparse argmax lands on row 0
+                                md = 0.0;
+                                sf = fb_row0;
+                                sn = row0[gs[c] >= 0 ? gs[c] : 0];
+                            }
+                            const double sc = fmax(fabs(sf), fabs(sn));
+                            if (vnode[c]) {
+                                small_any = small_any || (md < NUM_JAC_DIFF_REJECT * sc);
+                                const int slot = c * WAVE + lane;
+                                double fac = V[V_FAC * SLOTS + slot];
+                                if (md < NUM_JAC_DIFF_SMALL * sc) fac *= 10.0;
+                                if (md > NUM_JAC_DIFF_BIG * sc) fac *= 0.1;
+                                V[V_FAC * SLOTS + slot] = fmax(fac, NUM_JAC_MIN_FACTOR);
+                            }
+                            // J row i: (f_new[i] - f[i]) / h[column]
+                            const double hU = c == 0 ? hU0 : hj[c > 0 ? c - 1 : 0];
+                            const double hD = c == CPL - 1 ? hD0 : hj[c < CPL - 1 ? c + 1 : c];
+                            njl[c] = hasU && vnode[c] ? (jl[c] - fb[c]) / hU : 0.0;
+                            njd[c] = vnode[c] ? (jd[c] - fb[c]) / hj[c] : 0.0;
+                            nju[c] = hasD ? (ju[c] - fb[c]) / hD : 0.0;
+                        }
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            jl[c] = njl[c];
+                            jd[c] = njd[c];
+                            ju[c] = nju[c];
+                        }
+                        if (__any(small_any)) {
+                            // num_jac's "difference too small -> retry with 10x step" branch is not implemented;
+                            // it is counted so that no run can take it silently (never seen on this model).
+                            if (lane == 0) atomicAdd(&A.counters[0], 1ull);
+                        }
+                        if (jac_init) {
+                            // rest of BDF.__init__: D[0] = y, D[1] = f0 * h_abs, order = 1
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                const int slot = c * WAVE + lane;
+                                Dv[1 * SLOTS + slot] = Dv[1 * SLOTS + slot] * h_abs;
+                            }
+                            order = 1;
+                            n_equal = 0;
+                            have_lu = 0;
+                            phase = C_STEP_BEGIN;
+                        } else {
+                            have_lu = 0;
+                            current_jac = 1;
+                            phase = C_NEWTON_BEGIN;
+                        }
+                        need_rhs = false;
+                    } else if (phase == C_STEP_BEGIN) {
+                        // _step_impl entry
+                        min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+                        if (h_abs < min_step) {
+                            change_D<CPL>(Dv, ru, order, min_step / h_abs, lane);
+                            h_abs = min_step;
+                            n_equal = 0;
+                        }
+                        current_jac = 0;
+                        phase = C_STEP_TRY;
+                        need_rhs = false;
+                    } else if (phase == C_STEP_TRY) {
+                        need_rhs = false;
+                        if (h_abs < min_step) {
+                            phase = C_FAIL;
+                        } else {
+                            t_new = t + h_abs;
+                            if (t_new - tf > 0.0) {
+                                t_new = tf;
+                                change_D<CPL>(Dv, ru, order, fabs(t_new - t) / h_abs, lane);
+                                n_equal = 0;
+                                have_lu = 0;
+                            }
+                            const double h = t_new - t;
+                            h_abs = fabs(h);
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                const int slot = c * WAVE + lane;
+                                double s = Dv[slot], p = 0.0;
+                                for (int k = 1; k <= order; k++) {
+                                    const double dk = Dv[k * SLOTS + slot];
+                                    s += dk;
+                                    p += dk * gamma_k(k);
+                                }
+                                yp[c] = s;
+                                scl[c] = ATOL + RTOL * fabs(s);
+                                psiv[c] = p / alpha_k(order);
+                            }
+                            cc = h / alpha_k(order);
+                            phase = C_NEWTON_BEGIN;
+                        }
+                    } else if (phase == C_NEWTON_BEGIN) {
+                        if (!have_lu) {
+                            lu_factor<CPL>(F, jl, jd, ju, cc, lane, D);
+                            have_lu = 1;
+                            nlu++;
+                        }
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            dd[c] = 0.0;
+                            ycur[c] = yp[c];
+                        }
+                        newton_k = 0;
+                        dy_norm_old = -1.0;
+                        phase = PH_NEWTON;
+                    } else if (phase == PH_NEWTON) {
+                        // solve_bdf_system, iteration newton_k
+                        nfev++;
+                        bool fin = true;
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) fin = fin && (!vnode[c] || isfinite(f[c]));
+                        if (newton_k == 0) {
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) V[V_FP * SLOTS + c * WAVE + lane] = f[c];
+                        }
+                        bool converged = false, failed_newton = false;
+                        if (!__all(fin)) {
+                            failed_newton = true;
+                        } else {
+                            double dy[CPL];
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) dy[c] = vnode[c] ? cc * f[c] - psiv[c] - dd[c] : 0.0;
+                            lu_solve<CPL>(F, dy, lane);
+                            const double dy_norm = rms_ratio<CPL>(dy, scl, lane, D, inv_sqrt_d);
+                            const bool have_rate = dy_norm_old >= 0.0;
+                            const double rate = have_rate ? dy_norm / dy_norm_old : 0.0;
+                            double rp = rate;
+                            for (int q = 1; q < NEWTON_MAXITER - newton_k; q++) rp *= rate;
+                            if (have_rate && (rate >= 1.0 || rp / (1.0 - rate) * dy_norm > NEWTON_TOL)) {
+                                failed_newton = true;
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < CPL; c++) {
+                                    ycur[c] += dy[c];
+                                    dd[c] += dy[c];
+                                }
+                                if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < NEWTON_TOL)) {
+                                    converged = true;
+                                } else {
+                                    dy_norm_old = dy_norm;
+                                    newton_k++;
+                                    if (newton_k == NEWTON_MAXITER) failed_newton = true;
+                                }
+                            }
+                        }
+                        if (converged) {
+                            n_iter = newton_k + 1;
+                            phase = C_ERR_TEST;
+                            need_rhs = false;
+                        } else if (failed_newton) {
+                            phase = C_NEWTON_FAIL;
+                            need_rhs = false;
+                        }
+                    } else if (phase == C_NEWTON_FAIL) {
+                        need_rhs = false;
+                        if (current_jac) {
+                            h_abs *= 0.5;
+                            change_D<CPL>(Dv, ru, order, 0.5, lane);
+                            n_equal = 0;
+                            have_lu = 0;
+                            phase = C_STEP_TRY;
+                        } else {
+                            // J = jac(t_new, y_predict): base point yp, base f = fun(y_predict) kept in V_FP
+                            njev++;
+                            jac_init = 0;
+                            g = -1;
+                            phase = PH_JAC;
+                        }
+                    } else if (phase == C_ERR_TEST) {
+                        need_rhs = false;
+                        safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (double)(2 * NEWTON_MAXITER + n_iter);
+                        const double ec = error_const_k(order);
+                        double e[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            scl[c] = ATOL + RTOL * fabs(ycur[c]);
+                            e[c] = ec * dd[c];
+                        }
+                        error_norm = rms_ratio<CPL>(e, scl, lane, D, inv_sqrt_d);
+                        if (error_norm > 1.0) {
+                            const double factor = fmax(0.2, safety * pow(error_norm, -1.0 / (double)(order + 1)));
+                            h_abs *= factor;
+                            change_D<CPL>(Dv, ru, order, factor, lane);
+                            n_equal = 0;
+                            phase = C_STEP_TRY;
+                        } else {
+                            phase = C_ACCEPT;
+                        }
+                    } else if (phase == C_ACCEPT) {
+                        need_rhs = false;
+                        n_equal++;
+                        t = t_new;
+                        nsteps++;
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            const int slot = c * WAVE + lane;
+                            V[V_Y * SLOTS + slot] = ycur[c];        // sol.y[:, -1] so far
+                            Dv[(order + 2) * SLOTS + slot] = dd[c] - Dv[(order + 1) * SLOTS + slot];
+                            Dv[(order + 1) * SLOTS + slot] = dd[c];
+                            double acc = dd[c];
+                            for (int k = order; k >= 0; k--) {
+                                acc += Dv[k * SLOTS + slot];
+                                Dv[k * SLOTS + slot] = acc;
+                            }
+                        }
+                        if (t == tf) {
+                            phase = C_SUCCESS;
+                        } else if (n_equal < order + 1) {
+                            phase = C_STEP_BEGIN;
+                        } else {
+                            // order / step selection
+                            double em[CPL], ep[CPL];
+                            const double ecm = order > 1 ? error_const_k(order - 1) : 0.0;
+                            const double ecp = order < MAX_ORDER ? error_const_k(order + 1) : 0.0;
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                const int slot = c * WAVE + lane;
+                                em[c] = ecm * Dv[order * SLOTS + slot];
+                                ep[c] = ecp * Dv[(order + 2) * SLOTS + slot];
+                            }
+                            double nm = INFINITY, np_ = INFINITY;
+                            if (order > 1) nm = rms_ratio<CPL>(em, scl, lane, D, inv_sqrt_d);
+                            if (order < MAX_ORDER) np_ = rms_ratio<CPL>(ep, scl, lane, D, inv_sqrt_d);
+                            // three pow() in three lanes at once
+                            const double en = lane == 0 ? nm : (lane == 1 ? error_norm : np_);
+                            const double fk = pow(en, -1.0 / (double)(order + (lane < 3 ? lane : 2)));
+                            const double f0 = readlane_d(fk, 0), f1 = readlane_d(fk, 1), f2 = readlane_d(fk, 2);
+                            int best = 0;
+                            double fbest = f0;
+                            if (f1 > fbest) { best = 1; fbest = f1; }
+                            if (f2 > fbest) { best = 2; fbest = f2; }
+                            order += best - 1;
+                            const double factor = fmin(10.0, safety * fbest);
+                            h_abs *= factor;
+                            change_D<CPL>(Dv, ru, order, factor, lane);
+                            n_equal = 0;
+                            have_lu = 0;
+                            phase = C_STEP_BEGIN;
+                        }
+                    } else {
+                        ok = (phase == C_SUCCESS);
+                        break;
+                    }
+                }
+                st_nfev += nfev;
+                st_njev += njev;
+                st_nlu += nlu;
+                st_nsteps = nsteps;
+                if (ok) break;
+                // failed attempt: n_rnd *= 0.8 in place (richards_pde.py:522); restart from y0
+                failed++;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) V[V_NZ * SLOTS + c * WAVE + lane] *= 0.8;
+                if (!refresh) nscale *= 0.8;
+                __builtin_amdgcn_wave_barrier();
+                if (attempts >= 5) break;
+            }
+            if (failed) {
+                if (lane == 0) atomicAdd(&A.counters[1], (unsigned long long)failed);
+                if (!refresh && A.base_noise) {
+#pragma unroll
+                    for (int c = 0; c < CPL; c++)
+                        if (vnode[c]) A.base_noise[member * D + lane * CPL + c] = V[V_NZ * SLOTS + c * WAVE + lane];
+                }
+            }
+            if (refresh) fresh_seen++;
+        }
+        // ---- row epilogue: water table index (simulation.py:612), optional outputs
+        bool unsat[CPL];
+        double yv[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            yv[c] = V[V_Y * SLOTS + c * WAVE + lane];
+            unsat[c] = vnode[c] && !(yv[c] >= P.psi_sat);
+        }
+        const int istar = deepest_true<CPL>(unsat);
+        int w = istar < 0 ? 0 : istar + 1;
+        w = w < D - 1 ? w : D - 1;
+        if (skip) w = 0;
+        if (lane == 0) {
+            A.wtd_u16[(size_t)r * A.n_members + member] = (unsigned short)w;
+            if (A.stats) {
+                int *s = A.stats + ((size_t)r * A.n_members + member) * 6;
+                s[0] = st_nfev; s[1] = st_njev; s[2] = st_nlu; s[3] = st_nsteps; s[4] = attempts; s[5] = refresh;
+            }
+        }
+        if (A.psi_rows) {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                if (vnode[c]) A.psi_rows[((size_t)r * A.n_members + member) * D + lane * CPL + c] = skip ? 0.0 : yv[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; c++)
+        if (vnode[c]) A.psi[member * D + lane * CPL + c] = V[V_Y * SLOTS + c * WAVE + lane];
+    if (!A.base_noise && lane == 0) A.nscale[member] = nscale;
+}
+
+}  // namespace hc

@@ -1,0 +1,719 @@
+// hydrocol.hip -- C-ABI (include/hydrocol.h) and kernel launches for gfx950.
+// Host side is plain C++ over the HIP runtime; nothing here falls back to the CPU.
+#include "../../include/hydrocol.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hc_step.h"
+
+using namespace hc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(HC_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n && p) return HC_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        if (count == 0) return HC_OK;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        n = count;
+        return HC_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct hc_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_column = false, have_forcing = false, have_noise = false;
+    hc_column_params p{};
+    ColumnDev P{};
+    int cpl = 0, wpb = 0, slots = 0;
+    bool special = false;
+    DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d;
+    DevBuf<int> gtab, wtd_obs, draw_idx, stats, scratch_i;
+    DevBuf<unsigned char> daylight, refresh;
+    DevBuf<unsigned short> wtd_u16;
+    DevBuf<long long> moments;
+    DevBuf<unsigned long long> counters;
+    std::vector<unsigned char> h_refresh;
+    int64_t n_rows = 0, n_members = 0;
+    bool philox = false;
+    uint64_t seed = 0;
+    int64_t member_offset = 0;
+    int rows_per_launch = 48;
+};
+
+// ------------------------------------------------------------------ auxiliary kernels
+namespace hc {
+
+// per-row ensemble moments of the water-table index: one block per row, single writer
+__global__ void moments_kernel(const unsigned short *wtd, const int *wtd_obs, long long n_members,
+                               long long row_begin, int spinup, long long n_forcing, long long *moments)
+{
+    const int r = blockIdx.x;
+    const long long row = spinup ? row_begin : row_begin + r;
+    long long s1 = 0, s2 = 0;
+    for (long long k = threadIdx.x; k < n_members; k += blockDim.x) {
+        const long long w = wtd[(size_t)r * n_members + k];
+        s1 += w;
+        s2 += w * w;
+    }
+    __shared__ long long sh1[256], sh2[256];
+    sh1[threadIdx.x] = s1;
+    sh2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh1[threadIdx.x] += sh1[threadIdx.x + o];
+            sh2[threadIdx.x] += sh2[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && wtd_obs[row] >= 0) {
+        moments[row] += n_members;
+        moments[n_forcing + row] += sh1[0];
+        moments[2 * n_forcing + row] += sh2[0];
+    }
+}
+
+__global__ void widen_u16(const unsigned short *in, int *out, size_t n)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = in[k];
+}
+
+__global__ void fill_d(double *p, double v, size_t n)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) p[k] = v;
+}
+
+__global__ void broadcast_state(const double *src, double *dst, int D, long long n_members)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < (size_t)D * n_members) dst[k] = src[k % D];
+}
+
+__global__ void philox_dump(unsigned long long seed, long long member, unsigned draw, int D, double *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D) out[i] = philox_normal(seed, (unsigned long long)member, draw, (unsigned)i);
+}
+
+// RHS hook: one wave per member, same device path as the stepper
+template <int CPL, bool SPECIAL, int WPB>
+__global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, long long row, double *dydt,
+                                                            double *aux)
+{
+    constexpr int SLOTS = WAVE * CPL;
+    extern __shared__ double lds[];
+    double *tab = lds;
+    double *nzbase = tab + NTAB * SLOTS;
+    for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
+    __syncthreads();
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const long long member = (long long)blockIdx.x * WPB + wave;
+    if (member >= A.n_members) return;
+    double *nz = nzbase + wave * SLOTS;
+    const ColumnDev &P = A.P;
+    const int D = P.D;
+    RowDev R;
+    R.precip = A.precip[row];
+    R.atm = A.atm[row];
+    R.daylight = A.daylight[row];
+    R.wtd_obs = A.wtd_obs[row];
+    R.spinup = A.spinup;
+    double y[CPL], rnd[CPL], f[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = lane * CPL + c;
+        y[c] = i < D ? A.psi[member * D + i] : 0.0;
+        double z = 0.0;
+        if (i < D) {
+            if (A.base_noise)
+                z = A.base_noise[member * D + i];
+            else
+                z = philox_normal(A.seed, (unsigned long long)(A.member_offset + member), 0u, (unsigned)i) *
+                    A.nscale[member];
+        }
+        nz[c * WAVE + lane] = z;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = lane * CPL + c;
+        int idx = i >= 1 ? i - 1 : 0;
+        idx = (i < D - 1) ? idx : 0;
+        rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * nz[(idx % CPL) * WAVE + idx / CPL];
+    }
+    rhs_eval<CPL, SPECIAL>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr);
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = lane * CPL + c;
+        if (i < D) dydt[member * D + i] = f[c];
+    }
+}
+
+// plugin call on the nodes (diagnostics), one thread per (member, node)
+__global__ void model_nodes_kernel(const StepArgs A, const double *node_tabs, int special, double *out,
+                                   double *qinf)
+{
+    const ColumnDev &P = A.P;
+    const int D = P.D;
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)A.n_members * D;
+    if (k >= total) return;
+    const long long member = k / D;
+    const int i = (int)(k % D);
+    const double por = node_tabs[i], meank = node_tabs[D + i], noisec = node_tabs[2 * D + i];
+    const double mk = meank == 0.0 ? 1.0e-7 : meank;
+    double z;
+    if (A.base_noise)
+        z = A.base_noise[member * D + i];
+    else
+        z = philox_normal(A.seed, (unsigned long long)(A.member_offset + member), 0u, (unsigned)i) * A.nscale[member];
+    double th, K, C, kb, pf;
+    if (special)
+        model_cell<true>(P, A.psi[k], por, log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
+    else
+        model_cell<false>(P, A.psi[k], por, log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
+    out[k] = th;
+    out[total + k] = K;
+    out[2 * total + k] = C;
+    out[3 * total + k] = kb;
+    if (qinf && i == 0) qinf[member] = fmin(2.0 * (por - th) * P.dz, kb);
+}
+
+}  // namespace hc
+
+// ------------------------------------------------------------------ launch dispatch
+namespace {
+
+size_t step_lds_bytes(int cpl, int wpb)
+{
+    const size_t slots = (size_t)WAVE * cpl;
+    return NTAB * slots * 8 + 4 * slots * 4 + (size_t)wpb * (NVEC * slots + WAVE_SCRATCH) * 8;
+}
+size_t rhs_lds_bytes(int cpl, int wpb)
+{
+    const size_t slots = (size_t)WAVE * cpl;
+    return NTAB * slots * 8 + (size_t)wpb * slots * 8;
+}
+
+template <int CPL, bool SPECIAL, int WPB>
+int launch_step_t(hc_handle *h, const StepArgs &A)
+{
+    auto kern = step_kernel<CPL, SPECIAL, WPB>;
+    const size_t lds = step_lds_bytes(CPL, WPB);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    const unsigned grid = (unsigned)((A.n_members + WPB - 1) / WPB);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * WAVE), lds, h->stream, A);
+    HIP_TRY(hipGetLastError());
+    return HC_OK;
+}
+
+template <int CPL, bool SPECIAL, int WPB>
+int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
+{
+    auto kern = rhs_kernel<CPL, SPECIAL, WPB>;
+    const size_t lds = rhs_lds_bytes(CPL, WPB);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    const unsigned grid = (unsigned)((A.n_members + WPB - 1) / WPB);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * WAVE), lds, h->stream, A, row, dydt, aux);
+    HIP_TRY(hipGetLastError());
+    return HC_OK;
+}
+
+#define HC_DISPATCH(FN, ...)                                                            \
+    switch (h->cpl) {                                                                   \
+        case 2: return h->special ? FN<2, true, 4>(__VA_ARGS__) : FN<2, false, 4>(__VA_ARGS__); \
+        case 3: return h->special ? FN<3, true, 4>(__VA_ARGS__) : FN<3, false, 4>(__VA_ARGS__); \
+        case 4: return h->special ? FN<4, true, 4>(__VA_ARGS__) : FN<4, false, 4>(__VA_ARGS__); \
+        case 5: return h->special ? FN<5, true, 4>(__VA_ARGS__) : FN<5, false, 4>(__VA_ARGS__); \
+        default: break;                                                                 \
+    }                                                                                   \
+    return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= 320", h->p.dim_d, h->cpl)
+
+int launch_step(hc_handle *h, const StepArgs &A) { HC_DISPATCH(launch_step_t, h, A); }
+int launch_rhs(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
+{
+    HC_DISPATCH(launch_rhs_t, h, A, row, dydt, aux);
+}
+
+int fill_args(hc_handle *h, StepArgs &A)
+{
+    if (!h->have_column) return fail(HC_ERR_ARG, "hc_set_column has not been called");
+    if (!h->have_forcing) return fail(HC_ERR_ARG, "hc_set_forcing has not been called");
+    if (h->n_members <= 0 || !h->psi.p) return fail(HC_ERR_ARG, "hc_set_members / hc_set_state has not been called");
+    if (!h->have_noise) return fail(HC_ERR_ARG, "no noise source: call hc_set_noise_host or hc_set_noise_philox");
+    memset(&A, 0, sizeof(A));
+    A.P = h->P;
+    A.tab = h->tab.p;
+    A.gtab = h->gtab.p;
+    A.psi = h->psi.p;
+    A.base_noise = h->philox ? nullptr : h->base.p;
+    A.nscale = h->nscale.p;
+    A.precip = h->precip.p;
+    A.atm = h->atm.p;
+    A.daylight = h->daylight.p;
+    A.refresh = h->refresh.p;
+    A.wtd_obs = h->wtd_obs.p;
+    A.draw_idx = h->draw_idx.p;
+    A.n_members = h->n_members;
+    A.member_offset = h->member_offset;
+    A.seed = h->seed;
+    A.counters = h->counters.p;
+    return HC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C-ABI
+extern "C" {
+
+const char *hc_last_error(void) { return g_err.c_str(); }
+const char *hc_version(void) { return "hydrocol 0.1 (gfx950)"; }
+
+int hc_create(int device_ordinal, hc_handle **out)
+{
+    if (!out) return fail(HC_ERR_ARG, "hc_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(HC_ERR_NO_DEVICE, "no HIP device visible (%s): the hydrocol stepper has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return fail(HC_ERR_ARG, "device ordinal %d out of range [0,%d)", device_ordinal, count);
+    HIP_TRY(hipSetDevice(device_ordinal));
+    hc_handle *h = new hc_handle();
+    h->device = device_ordinal;
+    HIP_TRY(hipStreamCreate(&h->stream));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    if (h->counters.ensure(4) != HC_OK) return HC_ERR_DEVICE;
+    HIP_TRY(hipMemset(h->counters.p, 0, 4 * sizeof(unsigned long long)));
+    const char *rpl = getenv("HYDROCOL_ROWS_PER_LAUNCH");
+    if (rpl && atoi(rpl) > 0) h->rows_per_launch = atoi(rpl);
+    *out = h;
+    return HC_OK;
+}
+
+int hc_destroy(hc_handle *h)
+{
+    if (!h) return HC_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    h->tab.release(); h->node_tabs.release(); h->precip.release(); h->atm.release(); h->psi.release();
+    h->base.release(); h->nscale.release(); h->fresh.release(); h->psi_rows.release(); h->scratch_d.release();
+    h->gtab.release(); h->wtd_obs.release(); h->draw_idx.release(); h->stats.release(); h->scratch_i.release();
+    h->daylight.release(); h->refresh.release(); h->wtd_u16.release(); h->moments.release(); h->counters.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return HC_OK;
+}
+
+int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_tabs, const double *mid_tabs,
+                  const int32_t *groups)
+{
+    if (!h || !p || !node_tabs || !mid_tabs || !groups) return fail(HC_ERR_ARG, "hc_set_column: NULL argument");
+    const int D = p->dim_d;
+    if (D < 4 || D > HC_MAX_DEPTH_NODES) return fail(HC_ERR_ARG, "dim_d = %d outside [4, %d]", D, HC_MAX_DEPTH_NODES);
+    if (p->n_groups < 1 || p->n_groups > 16) return fail(HC_ERR_ARG, "n_groups = %d outside [1,16]", p->n_groups);
+    if (!(p->dz > 0.0) || !(p->n > 1.0) || !(p->alpha > 0.0)) return fail(HC_ERR_ARG, "bad dz / n / alpha");
+    if (p->n_root_first < 0 || p->n_root_first > 1 || p->n_root_int < 0 || p->n_root_int > D - 2)
+        return fail(HC_ERR_ARG, "bad root-zone cell counts");
+    for (int i = 0; i < D; i++)
+        if (groups[i] < 0 || groups[i] >= p->n_groups) return fail(HC_ERR_ARG, "groups[%d] out of range", i);
+    HIP_TRY(hipSetDevice(h->device));
+    h->p = *p;
+    int cpl = (D + WAVE - 1) / WAVE;
+    if (cpl < 2) cpl = 2;
+    h->cpl = cpl;
+    h->wpb = 4;
+    h->slots = WAVE * cpl;
+    h->special = (p->model == HC_MODEL_VRETTAS_FUNG && p->n == 2.0 && p->m == 0.5 && p->lambda_exp == 1.0);
+    ColumnDev &P = h->P;
+    P.D = D; P.model = p->model; P.flag_et = p->flag_et; P.flag_lf = p->flag_lf; P.flag_hlift = p->flag_hlift;
+    P.n_root_first = p->n_root_first; P.n_root_int = p->n_root_int; P.n_groups = p->n_groups;
+    P.theta_res = p->theta_res; P.alpha = p->alpha; P.n = p->n; P.m = p->m; P.psi_sat = p->psi_sat;
+    P.epsilon = p->epsilon; P.lambda = p->lambda_exp; P.sigma = p->sigma_noise; P.sat_soil = p->sat_soil;
+    P.dz = p->dz; P.inv_dz = 1.0 / p->dz; P.ipsi50 = p->ipsi50; P.lai = p->lai; P.surface_evap = p->surface_evap;
+    P.interception = p->interception; P.evap_delta_min = p->evap_delta_min;
+    P.mn_alpha = (p->m * p->n) * p->alpha;
+    P.inv_m = 1.0 / p->m;
+    P.por_node0 = node_tabs[0];
+
+    const int M = D - 1, S = h->slots;
+    std::vector<double> tab((size_t)NTAB * S);
+    std::vector<int> gt((size_t)NGTAB * S, -1);
+    auto put = [&](int slot, double por, double fc, double wlt, double root, double meank, double noisec) {
+        const double mk = meank == 0.0 ? 1.0e-7 : meank;   // utilities.py:50
+        tab[(size_t)T_POR * S + slot] = por;
+        tab[(size_t)T_FC * S + slot] = fc;
+        tab[(size_t)T_WLT * S + slot] = wlt;
+        tab[(size_t)T_ROOT * S + slot] = root;
+        tab[(size_t)T_LOGM * S + slot] = std::log(mk);
+        tab[(size_t)T_INVM2 * S + slot] = 1.0 / (mk * mk);
+        tab[(size_t)T_NOISEC * S + slot] = noisec;
+    };
+    for (int lane = 0; lane < WAVE; lane++)
+        for (int c = 0; c < cpl; c++) {
+            const int i = lane * cpl + c, slot = c * WAVE + lane;
+            if (i < M)
+                put(slot, mid_tabs[i], mid_tabs[M + i], mid_tabs[2 * M + i], mid_tabs[3 * M + i],
+                    mid_tabs[4 * M + i], mid_tabs[5 * M + i]);
+            else
+                put(slot, 0.3, 0.2, 0.1, 0.0, 1.0, 0.0);    // padding cell: benign, results masked
+            if (i < D) {
+                gt[(size_t)G_SELF * S + slot] = groups[i];
+                gt[(size_t)G_PREV * S + slot] = i >= 1 ? groups[i - 1] : -1;
+                gt[(size_t)G_NEXT * S + slot] = i < D - 1 ? groups[i + 1] : -1;
+            }
+        }
+    // virtual top-node cell in the always-free slot (lane 63, c = cpl-1)
+    put((cpl - 1) * WAVE + (WAVE - 1), node_tabs[0], 0.2, 0.1, 0.0, node_tabs[D + 0], node_tabs[2 * D + 0]);
+    if (h->tab.ensure(tab.size()) || h->gtab.ensure(gt.size()) || h->node_tabs.ensure((size_t)3 * D))
+        return HC_ERR_DEVICE;
+    HIP_TRY(hipMemcpy(h->tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->gtab.p, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->node_tabs.p, node_tabs, (size_t)3 * D * 8, hipMemcpyHostToDevice));
+    h->have_column = true;
+    return HC_OK;
+}
+
+int hc_set_forcing(hc_handle *h, int64_t n_rows, const double *precip, const double *atm,
+                   const uint8_t *daylight, const int32_t *wtd_obs, const uint8_t *refresh)
+{
+    if (!h || n_rows < 1 || !precip || !atm || !daylight || !wtd_obs || !refresh)
+        return fail(HC_ERR_ARG, "hc_set_forcing: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t T = (size_t)n_rows;
+    std::vector<int> draw(T, 0);
+    int cnt = 0;
+    for (size_t i = 0; i < T; i++) {
+        if (refresh[i]) cnt++;
+        draw[i] = cnt;
+    }
+    if (h->precip.ensure(T) || h->atm.ensure(T) || h->daylight.ensure(T) || h->refresh.ensure(T) ||
+        h->wtd_obs.ensure(T) || h->draw_idx.ensure(T) || h->moments.ensure(3 * T))
+        return HC_ERR_DEVICE;
+    HIP_TRY(hipMemcpy(h->precip.p, precip, T * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->atm.p, atm, T * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->daylight.p, daylight, T, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->refresh.p, refresh, T, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->wtd_obs.p, wtd_obs, T * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->draw_idx.p, draw.data(), T * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->moments.p, 0, 3 * T * 8));
+    h->h_refresh.assign(refresh, refresh + T);
+    h->n_rows = n_rows;
+    h->have_forcing = true;
+    return HC_OK;
+}
+
+int hc_set_members(hc_handle *h, int64_t n_members)
+{
+    if (!h || n_members < 1) return fail(HC_ERR_ARG, "hc_set_members: bad argument");
+    if (!h->have_column) return fail(HC_ERR_ARG, "hc_set_column must come first");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)n_members * h->p.dim_d;
+    if (h->psi.ensure(n) || h->nscale.ensure((size_t)n_members)) return HC_ERR_DEVICE;
+    hipLaunchKernelGGL(fill_d, dim3((unsigned)((n_members + 255) / 256)), dim3(256), 0, h->stream, h->nscale.p, 1.0,
+                       (size_t)n_members);
+    HIP_TRY(hipGetLastError());
+    h->n_members = n_members;
+    h->have_noise = false;
+    return HC_OK;
+}
+
+int hc_set_state(hc_handle *h, const double *psi, int broadcast)
+{
+    if (!h || !psi) return fail(HC_ERR_ARG, "hc_set_state: bad argument");
+    if (h->n_members <= 0) return fail(HC_ERR_ARG, "hc_set_members must come first");
+    HIP_TRY(hipSetDevice(h->device));
+    const int D = h->p.dim_d;
+    for (int i = 0; i < D; i++)
+        if (!std::isfinite(psi[i])) return fail(HC_ERR_ARG, "state entry %d is not finite", i);
+    const size_t n = (size_t)h->n_members * D;
+    if (broadcast) {
+        if (h->scratch_d.ensure(D)) return HC_ERR_DEVICE;
+        HIP_TRY(hipMemcpyAsync(h->scratch_d.p, psi, (size_t)D * 8, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(broadcast_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                           h->scratch_d.p, h->psi.p, D, (long long)h->n_members);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    } else {
+        HIP_TRY(hipMemcpy(h->psi.p, psi, n * 8, hipMemcpyHostToDevice));
+    }
+    return HC_OK;
+}
+
+int hc_get_state(hc_handle *h, double *psi, int64_t first, int64_t count)
+{
+    if (!h || !psi || first < 0 || count < 0 || first + count > h->n_members)
+        return fail(HC_ERR_ARG, "hc_get_state: bad range");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int D = h->p.dim_d;
+    HIP_TRY(hipMemcpy(psi, h->psi.p + (size_t)first * D, (size_t)count * D * 8, hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+
+int hc_set_noise_host(hc_handle *h, const double *base)
+{
+    if (!h || !base) return fail(HC_ERR_ARG, "hc_set_noise_host: bad argument");
+    if (h->n_members <= 0) return fail(HC_ERR_ARG, "hc_set_members must come first");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n_members * h->p.dim_d;
+    if (h->base.ensure(n)) return HC_ERR_DEVICE;
+    HIP_TRY(hipMemcpy(h->base.p, base, n * 8, hipMemcpyHostToDevice));
+    h->philox = false;
+    h->have_noise = true;
+    return HC_OK;
+}
+
+int hc_get_noise_base(hc_handle *h, double *base, int64_t first, int64_t count)
+{
+    if (!h || !base || h->philox || !h->base.p || first < 0 || count < 0 || first + count > h->n_members)
+        return fail(HC_ERR_ARG, "hc_get_noise_base: bad argument (host noise mode only)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int D = h->p.dim_d;
+    HIP_TRY(hipMemcpy(base, h->base.p + (size_t)first * D, (size_t)count * D * 8, hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+
+int hc_set_noise_philox(hc_handle *h, uint64_t seed, int64_t member_offset)
+{
+    if (!h || member_offset < 0) return fail(HC_ERR_ARG, "hc_set_noise_philox: bad argument");
+    if (h->n_members <= 0) return fail(HC_ERR_ARG, "hc_set_members must come first");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(fill_d, dim3((unsigned)((h->n_members + 255) / 256)), dim3(256), 0, h->stream, h->nscale.p,
+                       1.0, (size_t)h->n_members);
+    HIP_TRY(hipGetLastError());
+    h->seed = seed;
+    h->member_offset = member_offset;
+    h->philox = true;
+    h->have_noise = true;
+    return HC_OK;
+}
+
+int hc_philox_normals(hc_handle *h, int64_t member, int64_t draw, double *out)
+{
+    if (!h || !out || member < 0 || draw < 0) return fail(HC_ERR_ARG, "hc_philox_normals: bad argument");
+    if (!h->have_column) return fail(HC_ERR_ARG, "hc_set_column must come first");
+    HIP_TRY(hipSetDevice(h->device));
+    const int D = h->p.dim_d;
+    if (h->scratch_d.ensure(D)) return HC_ERR_DEVICE;
+    hipLaunchKernelGGL(philox_dump, dim3((D + 63) / 64), dim3(64), 0, h->stream, (unsigned long long)h->seed,
+                       (long long)member, (unsigned)draw, D, h->scratch_d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->scratch_d.p, (size_t)D * 8, hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+
+int hc_step_rows(hc_handle *h, hc_step_args *a)
+{
+    if (!h || !a) return fail(HC_ERR_ARG, "hc_step_rows: NULL argument");
+    StepArgs A;
+    int rc = fill_args(h, A);
+    if (rc) return rc;
+    if (a->n_rows < 0) return fail(HC_ERR_ARG, "n_rows < 0");
+    if (a->spinup) {
+        if (a->row_begin < 0 || a->row_begin >= h->n_rows) return fail(HC_ERR_ARG, "spin-up forcing row out of range");
+    } else if (a->row_begin < 1 || a->row_begin + a->n_rows > h->n_rows) {
+        return fail(HC_ERR_ARG, "rows [%lld, %lld) outside [1, %lld)", (long long)a->row_begin,
+                    (long long)(a->row_begin + a->n_rows), (long long)h->n_rows);
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    const int D = h->p.dim_d;
+    const int64_t N = h->n_members;
+    a->kernel_ms = 0.0;
+    a->launches = 0;
+    int64_t fresh_consumed = 0;
+    for (int64_t done = 0; done < a->n_rows;) {
+        const int chunk = (int)std::min<int64_t>(h->rows_per_launch, a->n_rows - done);
+        const int64_t row0 = a->spinup ? a->row_begin : a->row_begin + done;
+        int n_fresh = 0;
+        if (!a->spinup)
+            for (int r = 0; r < chunk; r++) n_fresh += h->h_refresh[(size_t)(row0 + r)] ? 1 : 0;
+        if (!h->philox && n_fresh > 0) {
+            if (!a->fresh_noise) return fail(HC_ERR_ARG, "host noise mode: fresh_noise is NULL but rows refresh");
+            const size_t cnt = (size_t)n_fresh * N * D;
+            if (h->fresh.ensure(cnt)) return HC_ERR_DEVICE;
+            HIP_TRY(hipMemcpyAsync(h->fresh.p, a->fresh_noise + (size_t)fresh_consumed * N * D, cnt * 8,
+                                   hipMemcpyHostToDevice, h->stream));
+        }
+        if (h->wtd_u16.ensure((size_t)chunk * N)) return HC_ERR_DEVICE;
+        if (a->stats_out && h->stats.ensure((size_t)chunk * N * 6)) return HC_ERR_DEVICE;
+        if (a->psi_rows_out && h->psi_rows.ensure((size_t)chunk * N * D)) return HC_ERR_DEVICE;
+        A.fresh = h->fresh.p;
+        A.row_begin = row0;
+        A.n_rows = chunk;
+        A.spinup = a->spinup;
+        A.wtd_u16 = h->wtd_u16.p;
+        A.stats = a->stats_out ? h->stats.p : nullptr;
+        A.psi_rows = a->psi_rows_out ? h->psi_rows.p : nullptr;
+        HIP_TRY(hipEventRecord(h->ev0, h->stream));
+        rc = launch_step(h, A);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(h->ev1, h->stream));
+        if (a->accumulate_moments) {
+            hipLaunchKernelGGL(moments_kernel, dim3(chunk), dim3(256), 0, h->stream, h->wtd_u16.p, h->wtd_obs.p,
+                               (long long)N, (long long)row0, (int)a->spinup, (long long)h->n_rows, h->moments.p);
+            HIP_TRY(hipGetLastError());
+        }
+        if (a->wtd_out) {
+            const size_t cnt = (size_t)chunk * N;
+            if (h->scratch_i.ensure(cnt)) return HC_ERR_DEVICE;
+            hipLaunchKernelGGL(widen_u16, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->wtd_u16.p,
+                               h->scratch_i.p, cnt);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(a->wtd_out + (size_t)done * N, h->scratch_i.p, cnt * 4, hipMemcpyDeviceToHost,
+                                   h->stream));
+        }
+        if (a->stats_out)
+            HIP_TRY(hipMemcpyAsync(a->stats_out + (size_t)done * N * 6, h->stats.p, (size_t)chunk * N * 6 * 4,
+                                   hipMemcpyDeviceToHost, h->stream));
+        if (a->psi_rows_out)
+            HIP_TRY(hipMemcpyAsync(a->psi_rows_out + (size_t)done * N * D, h->psi_rows.p, (size_t)chunk * N * D * 8,
+                                   hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        a->kernel_ms += ms;
+        a->launches++;
+        fresh_consumed += n_fresh;
+        done += chunk;
+    }
+    unsigned long long cnt[4];
+    HIP_TRY(hipMemcpy(cnt, h->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+    if (cnt[0] != 0)
+        return fail(HC_ERR_UNSUPPORTED,
+                    "%llu FD-Jacobian evaluations hit num_jac's retry-with-larger-step branch, which this build "
+                    "does not implement; results would differ from the reference", cnt[0]);
+    return HC_OK;
+}
+
+int hc_synchronize(hc_handle *h)
+{
+    if (!h) return fail(HC_ERR_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return HC_OK;
+}
+
+int hc_get_moments(hc_handle *h, int64_t *moments)
+{
+    if (!h || !moments || !h->have_forcing) return fail(HC_ERR_ARG, "hc_get_moments: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(moments, h->moments.p, (size_t)3 * h->n_rows * 8, hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+
+int hc_set_moments(hc_handle *h, const int64_t *moments)
+{
+    if (!h || !moments || !h->have_forcing) return fail(HC_ERR_ARG, "hc_set_moments: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(h->moments.p, moments, (size_t)3 * h->n_rows * 8, hipMemcpyHostToDevice));
+    return HC_OK;
+}
+
+int hc_reset_moments(hc_handle *h)
+{
+    if (!h || !h->have_forcing) return fail(HC_ERR_ARG, "hc_reset_moments: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemset(h->moments.p, 0, (size_t)3 * h->n_rows * 8));
+    return HC_OK;
+}
+
+int hc_rhs(hc_handle *h, int64_t row, int32_t spinup, double *dydt, double *aux)
+{
+    if (!h || !dydt) return fail(HC_ERR_ARG, "hc_rhs: NULL argument");
+    StepArgs A;
+    int rc = fill_args(h, A);
+    if (rc) return rc;
+    if (row < 0 || row >= h->n_rows) return fail(HC_ERR_ARG, "row out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const int D = h->p.dim_d;
+    const size_t n = (size_t)h->n_members * D, na = (size_t)h->n_members * (3 * (D - 1) + 1);
+    if (h->scratch_d.ensure(n + (aux ? na : 0))) return HC_ERR_DEVICE;
+    A.spinup = spinup;
+    rc = launch_rhs(h, A, row, h->scratch_d.p, aux ? h->scratch_d.p + n : nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(dydt, h->scratch_d.p, n * 8, hipMemcpyDeviceToHost));
+    if (aux) HIP_TRY(hipMemcpy(aux, h->scratch_d.p + n, na * 8, hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+
+int hc_model_nodes(hc_handle *h, double *out, double *qinf)
+{
+    if (!h || !out) return fail(HC_ERR_ARG, "hc_model_nodes: NULL argument");
+    StepArgs A;
+    int rc = fill_args(h, A);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    const int D = h->p.dim_d;
+    const size_t n = (size_t)h->n_members * D;
+    if (h->scratch_d.ensure(4 * n + (size_t)h->n_members)) return HC_ERR_DEVICE;
+    hipLaunchKernelGGL(model_nodes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, A,
+                       h->node_tabs.p, (int)h->special, h->scratch_d.p, h->scratch_d.p + 4 * n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, h->scratch_d.p, 4 * n * 8, hipMemcpyDeviceToHost));
+    if (qinf) HIP_TRY(hipMemcpy(qinf, h->scratch_d.p + 4 * n, (size_t)h->n_members * 8, hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+
+}  // extern "C"

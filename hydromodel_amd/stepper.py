@@ -1,0 +1,174 @@
+"""EnsembleStepper: Python face of one libhydrocol handle (one GPU, one parameter point).
+
+Mirrors what ``Simulation.run`` does per row (``/root/reference/code/src/simulation.py:576-626``)
+for N ensemble members at once; see include/hydrocol.h for the entry points.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def column_params(cols, surface_evap, flags=None):
+    """Fill hc_column_params from a digest.ColumnTables."""
+    fl = dict(cols.flags)
+    if flags:
+        fl.update(flags)
+    if fl.get("PREDICT"):
+        # richards_pde.py:327-330 raises TypeError on every NumPy >= 1.18 (float `low_lim`): the
+        # reference cannot run this mode, so there is nothing to match.
+        raise TypeError("'numpy.float64' object cannot be interpreted as an integer "
+                        "(PREDICT mode is broken in the reference: richards_pde.py:327-330)")
+    p = L.ColumnParams()
+    p.dim_d, p.model = cols.dim_d, cols.model
+    p.flag_et, p.flag_lf, p.flag_hlift = int(fl["ET"]), int(fl["LF"]), int(fl["HLIFT"])
+    p.n_root_first, p.n_root_int, p.n_groups = cols.n_root_first, cols.n_root_int, cols.n_groups
+    p.theta_res, p.alpha, p.n, p.m = cols.theta.res, cols.soil.alpha, cols.soil.n, cols.soil.m
+    p.psi_sat, p.epsilon = cols.soil.psi_sat, max(cols.soil.epsilon, 1.0e-8)
+    p.lambda_exp, p.sigma_noise, p.sat_soil = (cols.k_hc.lambda_exponent, cols.k_hc.sigma_noise,
+                                               cols.k_hc.sat_soil)
+    p.dz, p.ipsi50, p.lai = cols.dz, cols.ipsi50, cols.lai
+    p.surface_evap, p.interception = surface_evap, cols.interception
+    p.evap_delta_min = cols.evap_delta_min
+    return p
+
+
+class EnsembleStepper:
+    """N members x D depth nodes on one MI355X."""
+
+    def __init__(self, cols, forcing, n_members, device=0, flags=None):
+        self.lib = L.load()
+        self.cols, self.forcing = cols, forcing
+        self.D, self.N, self.T = cols.dim_d, int(n_members), forcing.dim_t
+        h = C.c_void_p()
+        L.check(self.lib.hc_create(int(device), C.byref(h)))
+        self.h = h
+        self.params = column_params(cols, forcing.surface_evap, flags)
+        node, mid = L.as_f64(cols.node_table()), L.as_f64(cols.mid_table())
+        groups = np.ascontiguousarray(cols.groups, dtype=np.int32)
+        L.check(self.lib.hc_set_column(self.h, C.byref(self.params), L.dptr(node), L.dptr(mid), L.iptr(groups)))
+        precip, atm = L.as_f64(forcing.precip), L.as_f64(forcing.atm)
+        day = np.ascontiguousarray(forcing.daylight, dtype=np.uint8)
+        wobs = np.ascontiguousarray(forcing.wtd_obs, dtype=np.int32)
+        refr = np.ascontiguousarray(forcing.refresh, dtype=np.uint8)
+        L.check(self.lib.hc_set_forcing(self.h, self.T, L.dptr(precip), L.dptr(atm), L.bptr(day),
+                                        L.iptr(wobs), L.bptr(refr)))
+        L.check(self.lib.hc_set_members(self.h, self.N))
+        self.last_kernel_ms = 0.0
+        self.last_launches = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # -- state / noise -------------------------------------------------------------
+    def set_state(self, psi):
+        psi = L.as_f64(psi)
+        if psi.shape == (self.D,):
+            L.check(self.lib.hc_set_state(self.h, L.dptr(psi), 1))
+        elif psi.shape == (self.N, self.D):
+            L.check(self.lib.hc_set_state(self.h, L.dptr(psi), 0))
+        else:
+            raise ValueError(f"state must be [{self.D}] or [{self.N}, {self.D}], got {psi.shape}")
+
+    def get_state(self, first=0, count=None):
+        count = self.N - first if count is None else count
+        out = np.empty((count, self.D))
+        L.check(self.lib.hc_get_state(self.h, L.dptr(out), first, count))
+        return out
+
+    def set_noise_host(self, base):
+        base = L.as_f64(base)
+        if base.shape != (self.N, self.D):
+            raise ValueError(f"base noise must be [{self.N}, {self.D}]")
+        L.check(self.lib.hc_set_noise_host(self.h, L.dptr(base)))
+
+    def get_noise_base(self, first=0, count=None):
+        count = self.N - first if count is None else count
+        out = np.empty((count, self.D))
+        L.check(self.lib.hc_get_noise_base(self.h, L.dptr(out), first, count))
+        return out
+
+    def set_noise_philox(self, seed, member_offset=0):
+        L.check(self.lib.hc_set_noise_philox(self.h, int(seed), int(member_offset)))
+
+    def philox_normals(self, member, draw):
+        out = np.empty(self.D)
+        L.check(self.lib.hc_philox_normals(self.h, int(member), int(draw), L.dptr(out)))
+        return out
+
+    # -- stepping ------------------------------------------------------------------
+    def n_refresh(self, row_begin, n_rows):
+        return int(self.forcing.refresh[row_begin:row_begin + n_rows].sum())
+
+    def step_rows(self, row_begin, n_rows, fresh_noise=None, spinup=False, moments=True,
+                  want_wtd=False, want_stats=False, want_psi=False):
+        a = L.StepArgs()
+        a.row_begin, a.n_rows, a.spinup, a.accumulate_moments = int(row_begin), int(n_rows), int(spinup), int(moments)
+        keep = []
+        if fresh_noise is not None:
+            fresh_noise = L.as_f64(fresh_noise)
+            need = 0 if spinup else self.n_refresh(row_begin, n_rows)
+            if fresh_noise.size != need * self.N * self.D:
+                raise ValueError(f"fresh_noise must hold {need} x [{self.N}, {self.D}] values")
+            a.fresh_noise = L.dptr(fresh_noise)
+            keep.append(fresh_noise)
+        out = {}
+        if want_wtd:
+            out["wtd"] = np.zeros((n_rows, self.N), dtype=np.int32)
+            a.wtd_out = L.iptr(out["wtd"])
+        if want_stats:
+            out["stats"] = np.zeros((n_rows, self.N, 6), dtype=np.int32)
+            a.stats_out = L.iptr(out["stats"])
+        if want_psi:
+            out["psi"] = np.zeros((n_rows, self.N, self.D))
+            a.psi_rows_out = L.dptr(out["psi"])
+        L.check(self.lib.hc_step_rows(self.h, C.byref(a)))
+        self.last_kernel_ms, self.last_launches = a.kernel_ms, a.launches
+        out["kernel_ms"], out["launches"] = a.kernel_ms, a.launches
+        return out
+
+    def moments(self):
+        m = np.zeros((3, self.T), dtype=np.int64)
+        L.check(self.lib.hc_get_moments(self.h, L.lptr(m)))
+        return m
+
+    def set_moments(self, m):
+        m = np.ascontiguousarray(m, dtype=np.int64)
+        L.check(self.lib.hc_set_moments(self.h, L.lptr(m)))
+
+    def reset_moments(self):
+        L.check(self.lib.hc_reset_moments(self.h))
+
+    # -- hooks ----------------------------------------------------------------------
+    def rhs(self, row, spinup=False, want_aux=False):
+        out = np.empty((self.N, self.D))
+        M = self.D - 1
+        aux = np.empty((self.N, 3 * M + 1)) if want_aux else None
+        L.check(self.lib.hc_rhs(self.h, int(row), int(spinup), L.dptr(out), L.dptr(aux) if want_aux else None))
+        if not want_aux:
+            return out
+        return out, {"c": aux[:, :M], "s": aux[:, M:2 * M], "f": aux[:, 2 * M:3 * M], "pL": aux[:, 3 * M]}
+
+    def model_nodes(self):
+        out = np.empty((4, self.N, self.D))
+        qinf = np.empty(self.N)
+        L.check(self.lib.hc_model_nodes(self.h, L.dptr(out), L.dptr(qinf)))
+        return {"theta": out[0], "K": out[1], "C": out[2], "K_bkg": out[3], "q_inf_max": qinf}
+
+
+def moments_to_mean_std(moments, dz):
+    """mu/sigma of the water-table depth [cm] per row from (count, sum idx, sum idx^2)."""
+    cnt = moments[0].astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mean_idx = moments[1] / cnt
+        var_idx = np.maximum(moments[2] / cnt - mean_idx ** 2, 0.0)
+    return dz * mean_idx, dz * np.sqrt(var_idx)
