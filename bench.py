@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- ensemble column-days/s of the MI355X Richards-column stepper.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE SIMULATED DAY (48 half-hour forcing rows) for every member of the rank's
+shard.  Workload (BASELINE.json configs[2], the one the metric is quoted on): 262 144 members
+per GPU, D = 300 depth nodes, 10-year synthetic forcing digest (175 200 rows), fp64, Philox
+noise generated in-kernel, shared initial condition from the member-0 spin-up; the timed region
+covers the K days after the W warm-up days (a prefix of the 10-year run -- SURVEY.md §8d).
+Members shard across ranks with no communication while stepping ("weak" scaling: per-GPU
+members fixed); the single collective -- the int64 all-reduce of the per-row water-table
+moments over RCCL -- runs after the timed region and is reported separately.
+
+Prints ONE JSON line (rank 0).  roofline.achieved uses the algorithmic bytes of SURVEY.md §8d,
+(16*D + 16) B per column-step, over the step kernel's mean launch duration measured with HIP
+events on the library's stream.  cpu_baseline times the C oracle (oracle/, a port of the same
+algorithm) on the host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+ROWS_PER_DAY = 48
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--members", type=int, default=262144, help="members per GPU")
+    ap.add_argument("--depth", type=int, default=300)
+    ap.add_argument("--years", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cols, forcing, psi0, threads, rows, members_per_thread, seed=5):
+    """Oracle (CPU port) on `threads` host threads; returns column-days/s and what was run."""
+    from oracle.oracle import Oracle, lib
+    lib()
+    D = cols.dim_d
+    n_ref = int(forcing.refresh[1:1 + rows].sum())
+
+    def work(tid):
+        orc = Oracle(cols, forcing.surface_evap)
+        rng = np.random.default_rng(seed + tid)
+        for _ in range(members_per_thread):
+            orc.run(forcing, psi0, rng.standard_normal(D), rng.standard_normal((max(n_ref, 1), D)), 1, 1 + rows)
+        return members_per_thread
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        done = sum(ex.map(work, range(threads)))
+    wall = time.perf_counter() - t0
+    days = done * rows / ROWS_PER_DAY
+    return {"value": days / wall, "unit": "column-days/s", "cores": threads, "kind": "port",
+            "sample": f"{done} members x {rows} rows (D={D}) of the same forcing, C oracle, "
+                      f"{threads} threads, {wall:.1f} s wall"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import EnsembleSimulation, allreduce_moments, spinup_on_gpu
+    from hydromodel_amd.stepper import EnsembleStepper
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+
+    params = default_parameters()
+    cols = ColumnTables(params, synthetic_well(args.depth))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(args.years), cols)
+    D, N = cols.dim_d, args.members
+    need_rows = 1 + (args.warmup + args.steps) * ROWS_PER_DAY
+    if need_rows > forcing.dim_t:
+        raise SystemExit(f"forcing has {forcing.dim_t} rows, need {need_rows}")
+
+    # shared initial condition: every rank computes the same member-0 spin-up (deterministic)
+    probe = EnsembleStepper(cols, forcing, 1, device=local_rank)
+    probe.set_noise_philox(args.seed, 0)
+    n_rnd0 = probe.philox_normals(0, 0)
+    probe.close()
+    psi0, spin_iters, _ = spinup_on_gpu(cols, forcing, n_rnd0, device=local_rank)
+
+    sim = EnsembleSimulation(cols, forcing, N, seed=args.seed, device=local_rank,
+                             member_offset=rank * N, psi0=psi0)
+    for _ in range(args.warmup):
+        sim.advance(ROWS_PER_DAY)
+    sim.kernel_ms, sim.launches = 0.0, 0
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.advance(ROWS_PER_DAY)          # hc_step_rows synchronises the library's stream
+    sync()
+    elapsed = time.perf_counter() - t0
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
+
+    # the one collective of the path: moments all-reduce (outside the timed region)
+    t1 = time.perf_counter()
+    moments = allreduce_moments(sim.moments(), dev)
+    torch.cuda.synchronize()
+    allreduce_s = time.perf_counter() - t1
+    mean_cm, std_cm = sim.wtd_mean_std(moments)
+    last_row = sim.next_row - 1
+
+    col_days = float(N) * world * args.steps
+    value = col_days / elapsed
+    rows_per_launch = ROWS_PER_DAY * args.steps / max(sim.launches, 1)
+    bytes_per_launch = float(N) * rows_per_launch * (16 * D + 16)
+    launch_ms = sim.kernel_ms / max(sim.launches, 1)
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "ensemble column-days/sec", "value": value, "unit": "column-days/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{N} members/GPU x D={D}, {args.years}-yr half-hourly synthetic forcing "
+                               f"({forcing.dim_t} rows), vrettas_fung + Stratified, ET+LF on; timed prefix = "
+                               f"days {args.warmup + 1}..{args.warmup + args.steps}",
+                   "members_per_gpu": N, "depth_nodes": D, "rows_per_step": ROWS_PER_DAY,
+                   "noise": "philox4x32-10 in-kernel", "parallelism": f"members sharded x{world}, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "hc::step_kernel", "launch_ms": launch_ms, "launches": sim.launches,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "note": "path is fp64-VALU/recurrence bound (SURVEY.md §8d): ~24 RHS evaluations per "
+                             "column-step at ~10^2 flop per byte of state"},
+        "moments_allreduce_s": allreduce_s,
+        "wtd_mean_cm_last_row": float(mean_cm[last_row]), "wtd_std_cm_last_row": float(std_cm[last_row]),
+        "spinup_iterations": spin_iters,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(cols, forcing, psi0, threads, rows=4 * ROWS_PER_DAY,
+                                           members_per_thread=32)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    sim.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""Ensemble driver: N stochastic realisations of one soil column on one GPU (one rank).
+
+Per-member semantics are those of ``Simulation.run`` (``/root/reference/code/src/simulation.py:495-672``):
+member k has its own noise stream, all members share forcing, tables and (by default) the
+initial condition produced by the spin-up of ``Simulation.initial_conditions`` (``:389-493``).
+Ranks shard members with no communication while stepping; the only collective is the final
+all-reduce of the per-row water-table moments (see :func:`allreduce_moments`).
+"""
+import numpy as np
+
+from .stepper import EnsembleStepper, moments_to_mean_std
+
+
+def pressure_head(cols, theta):
+    """Inverse van Genuchten -- ``HydrologicalModel.pressure_head`` (hydrological_model.py:43-119).
+
+    The reference interpolates the porosity AT the grid knots here (``self.porous(z)`` with the
+    full grid), i.e. ``cols.por_node``.  Returns (psi, s_eff).
+    """
+    theta = np.atleast_1d(np.asarray(theta, dtype=float))
+    if theta.shape[0] != cols.dim_d:
+        raise ValueError(f" HydrologicalModel: Input size dimensions don't match:"
+                         f" {theta.shape[0]} not equal to {cols.dim_d}.")
+    soil = cols.soil
+    eps = max(soil.epsilon, 1.0e-8)
+    por = cols.por_node
+    delta_s = por - cols.theta.res
+    q = np.minimum(np.maximum(theta, cols.theta.res), por)
+    s_eff = np.minimum(np.maximum((q - cols.theta.res) / delta_s, eps), 1.0)
+    id_sat = s_eff >= 0.99998
+    psi = np.zeros(theta.shape)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        psi[~id_sat] = -((s_eff[~id_sat] ** (-1.0 / soil.m) - 1.0) ** (1.0 / soil.n)) / soil.alpha
+    psi[id_sat] = np.arange(0, np.sum(id_sat)) * cols.dz
+    psi[~np.isfinite(psi)] = -1.0e+5
+    return psi, s_eff
+
+
+def spinup_on_gpu(cols, forcing, n_rnd, device=0, burn_in=1500, flags=None, verbose=False, well_no=None):
+    """``Simulation.initial_conditions`` (simulation.py:389-493) with the solves on the GPU.
+
+    Forcing row 0, fixed noise vector, SPINUP semantics, t_span = (0, 1); stops when the
+    estimated water table is within 2*dz of the first observation and the mean squared change
+    of the state is <= 0.01.  Returns (psi0, iterations, early_stop).
+    """
+    z = cols.z
+    y0, _ = pressure_head(cols, cols.por_raw)
+    st = EnsembleStepper(cols, forcing, 1, device=device, flags=flags)
+    try:
+        st.set_state(y0)
+        st.set_noise_host(np.asarray(n_rnd, dtype=float)[None, :])
+        early_stop, j = False, -1
+        for j in range(burn_in):
+            out = st.step_rows(0, 1, spinup=True, moments=False, want_wtd=True)
+            y_j = st.get_state()[0]
+            wtd_est = int(out["wtd"][0, 0])
+            abs_error = np.abs(forcing.zwtd_cm[0] - z[wtd_est])
+            mse_0 = np.mean((y_j - y0) ** 2)
+            y0 = y_j.copy()
+            if abs_error <= (2.0 * cols.dz) and (mse_0 <= 0.01):
+                early_stop = True
+                if verbose:
+                    print(f" [Initial Conditions for Well no. {well_no}]"
+                          f" finished at [itr: {j}] with [abs(error): {abs_error}]"
+                          f" and [MSE: {mse_0}]")
+                break
+        if verbose and not early_stop:
+            print(f" [Initial Conditions for Well no. {well_no}]"
+                  f" finished at maximum number of iterations.")
+    finally:
+        st.close()
+    return y0, j + 1, early_stop
+
+
+class EnsembleSimulation:
+    """N members of one parameter point on one device; Philox noise generated in-kernel."""
+
+    def __init__(self, cols, forcing, n_members, seed=0, device=0, member_offset=0, psi0=None, flags=None):
+        self.cols, self.forcing = cols, forcing
+        self.n_members = int(n_members)
+        self.member_offset = int(member_offset)
+        self.seed = int(seed)
+        self.device = device
+        if psi0 is None:
+            # shared initial condition: spin-up with the noise vector of global member 0, draw 0
+            probe = EnsembleStepper(cols, forcing, 1, device=device, flags=flags)
+            probe.set_noise_philox(self.seed, 0)
+            n_rnd = probe.philox_normals(0, 0)
+            probe.close()
+            psi0, self.spinup_iters, _ = spinup_on_gpu(cols, forcing, n_rnd, device=device, flags=flags)
+        self.psi0 = np.asarray(psi0, dtype=float)
+        self.stepper = EnsembleStepper(cols, forcing, self.n_members, device=device, flags=flags)
+        self.stepper.set_state(self.psi0)
+        self.stepper.set_noise_philox(self.seed, self.member_offset)
+        self.next_row = 1
+        self.kernel_ms = 0.0
+        self.launches = 0
+
+    def advance(self, n_rows, **kw):
+        """Solve the next ``n_rows`` forcing rows for every member."""
+        out = self.stepper.step_rows(self.next_row, n_rows, **kw)
+        self.next_row += n_rows
+        self.kernel_ms += out["kernel_ms"]
+        self.launches += out["launches"]
+        return out
+
+    def moments(self):
+        return self.stepper.moments()
+
+    def wtd_mean_std(self, moments=None):
+        m = self.moments() if moments is None else moments
+        return moments_to_mean_std(m, self.cols.dz)
+
+    def close(self):
+        self.stepper.close()
+
+
+def allreduce_moments(moments, device):
+    """Sum the [3][T] int64 moment table over all ranks (RCCL when the backend is nccl).
+
+    Integer sums are exact and order-independent, so the ensemble mean / sigma are bitwise
+    identical at any GPU count.  No-op when torch.distributed is not initialised.
+    """
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return moments
+    t = torch.from_numpy(np.ascontiguousarray(moments))
+    if dist.get_backend() == "nccl":
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
