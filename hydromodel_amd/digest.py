@@ -164,7 +164,7 @@ def porosity_profiles(z_grid, layers, theta, soil, p_model):
             p1 = np.log(p0 / theta.min) / z_grid[-1]
             q_sat[web] = p0 * np.exp(-np.linspace(0, l_fbed, web.sum()) * p1)
     elif kind == "NOISY":
-        # porosity.py:122-158 draws from an UNSEEDED generator: not reproducible, no oracle.
+        # porosity.py:122-158 draws from an UNSEEDED generator: not reproducible, nothing to check against.
         raise ValueError(" Porosity: profile type 'Noisy' is not supported by the ensemble stepper "
                          "(unseeded RNG in the reference, porosity.py:124).")
     else:

@@ -1,0 +1,74 @@
+"""The C-ABI library loads and exports every symbol include/hydrocol.h declares (no GPU needed)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _declared():
+    text = (REPO / "include" / "hydrocol.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hc_[a-z_0-9]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from hydromodel_amd import _lib
+    return _lib.load()
+
+
+def test_header_and_binding_agree(lib):
+    from hydromodel_amd import _lib
+    declared = _declared()
+    assert len(declared) >= 20
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in _declared():
+        assert hasattr(lib, name), name
+
+
+def test_struct_sizes():
+    from hydromodel_amd import _lib
+    assert C.sizeof(_lib.ColumnParams) == 8 * 4 + 15 * 8
+    assert C.sizeof(_lib.StepArgs) == 8 + 8 + 4 + 4 + 4 * 8 + 8 + 8
+
+
+def test_version_string(lib):
+    assert b"gfx950" in lib.hc_version()
+
+
+def test_fails_loudly_without_a_device(lib):
+    """No CPU path: on a box without a GPU hc_create must fail with a message, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible; the no-device path cannot be exercised here")
+    from hydromodel_amd import _lib
+    h = C.c_void_p()
+    rc = lib.hc_create(0, C.byref(h))
+    assert rc in (-2, -3) and not h.value
+    assert b"no CPU path" in lib.hc_last_error() or b"failed" in lib.hc_last_error()
+    with pytest.raises(_lib.HcError):
+        _lib.check(rc)
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from hydromodel_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.HcError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/ (it is the checker)."""
+    pat = re.compile(r"import\s+oracle|from\s+oracle|oracle[/.]|hydro_oracle|ho_[a-z_]+\(")
+    for path in (REPO / "hydromodel_amd").rglob("*"):
+        if path.suffix in (".py", ".hip", ".h", ".cpp"):
+            assert not pat.search(path.read_text()), path
