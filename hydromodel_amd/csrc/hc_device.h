@@ -19,7 +19,8 @@ namespace hc {
 constexpr int WAVE = 64;
 
 // slot tables staged in LDS, [NTAB][64*CPL] doubles
-enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, NTAB };
+enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, T_INVDELTA, T_INVD1, NTAB };
+// T_INVDELTA = 1/(por - theta_res), T_INVD1 = 1/(por - wlt) (a zero denominator counts as 1)
 // per-slot integer tables, [NGTAB][64*CPL]
 enum { G_SELF = 0, G_PREV, G_NEXT, NGTAB };
 
@@ -54,44 +55,92 @@ __device__ __forceinline__ double uniform_d(double v)
 }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// DPP move of a double: lanes without a source keep `old`
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ double dpp_d(double v, double old)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, ROWMASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140,
+              DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138, DPP_WAVE_SHL1 = 0x130;
+template <int N> struct dpp_row_shr { static constexpr int value = 0x110 + N; };
+
+// wave-wide sum, result uniform (no LDS traffic: 6 DPP steps + readlane)
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return uniform_d(v);
+    v += dpp_d<DPP_QUAD_XOR1>(v, 0.0);
+    v += dpp_d<DPP_QUAD_XOR2>(v, 0.0);
+    v += dpp_d<DPP_ROW_HALF_MIRROR>(v, 0.0);
+    v += dpp_d<DPP_ROW_MIRROR>(v, 0.0);
+    v += dpp_d<DPP_ROW_BCAST15, 0xa>(v, 0.0);
+    v += dpp_d<DPP_ROW_BCAST31, 0xc>(v, 0.0);
+    return readlane_d(v, WAVE - 1);
 }
 __device__ __forceinline__ void wave_sum2(double &a, double &b)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double ta = __shfl_xor(a, o, WAVE), tb = __shfl_xor(b, o, WAVE);
-        a += ta;
-        b += tb;
-    }
-    a = uniform_d(a);
-    b = uniform_d(b);
+    a = wave_sum(a);
+    b = wave_sum(b);
 }
-// exclusive prefix sum across lanes
+// exclusive prefix sum across lanes (Hillis-Steele inside 16-lane rows, then row broadcasts)
 __device__ __forceinline__ double wave_excl_scan(double v, int lane)
 {
-    double incl = v;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        double t = __shfl_up(incl, o, WAVE);
-        if (lane >= o) incl += t;
-    }
-    double ex = __shfl_up(incl, 1, WAVE);
-    return lane == 0 ? 0.0 : ex;
+    (void)lane;
+    v += dpp_d<dpp_row_shr<1>::value>(v, 0.0);
+    v += dpp_d<dpp_row_shr<2>::value>(v, 0.0);
+    v += dpp_d<dpp_row_shr<4>::value>(v, 0.0);
+    v += dpp_d<dpp_row_shr<8>::value>(v, 0.0);
+    v += dpp_d<DPP_ROW_BCAST15, 0xa>(v, 0.0);
+    v += dpp_d<DPP_ROW_BCAST31, 0xc>(v, 0.0);
+    return dpp_d<DPP_WAVE_SHR1>(v, 0.0);
 }
+// value of lane-1 / lane+1 (`fill` at the wave edge)
 __device__ __forceinline__ double shfl_up1(double v, int lane, double fill)
 {
-    double t = __shfl_up(v, 1, WAVE);
-    return lane == 0 ? fill : t;
+    (void)lane;
+    return dpp_d<DPP_WAVE_SHR1>(v, fill);
 }
 __device__ __forceinline__ double shfl_down1(double v, int lane, double fill)
 {
-    double t = __shfl_down(v, 1, WAVE);
-    return lane == WAVE - 1 ? fill : t;
+    (void)lane;
+    return dpp_d<DPP_WAVE_SHL1>(v, fill);
+}
+
+// log(x) for finite x >= 1 (argument of the log-normal transform): fdlibm's e_log kernel,
+// < 1 ulp, without the special-case ladder of the library routine
+__device__ __forceinline__ double log_ge1(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 +
+                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+// sqrt(x) for 0 <= x < ~1e300, no denormal scaling (Newton on v_rsq_f64, two residual corrections)
+__device__ __forceinline__ double sqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;
 }
 
 // ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
@@ -128,9 +177,9 @@ __device__ __forceinline__ double philox_normal(uint64_t seed, uint64_t member, 
 // SPECIAL: vrettas_fung with n = 2, m = 1/2, lambda = 1 (the reference's input_parameters.json);
 // pow() disappears.  Generic path keeps pow() and the model switch.
 template <bool SPECIAL>
-__device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, double por, double logm,
-                                           double invm2, double noisec, double rnd, double &theta,
-                                           double &K, double &C, double &kb, double &pfac)
+__device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, double por, double inv_delta,
+                                           double logm, double invm2, double noisec, double rnd,
+                                           double &theta, double &K, double &C, double &kb, double &pfac)
 {
     const double delta = por - P.theta_res;
     const bool sat = psi >= P.psi_sat;
@@ -141,7 +190,8 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
         pfac = pow(1.0 + pow(ap, P.n), -P.m);
     double q = P.theta_res + delta * pfac;
     q = sat ? por : q;
-    double s = (q - P.theta_res) / delta;
+    double s = (q - P.theta_res) / delta;   // a true division: 1 - s is ill-conditioned near saturation
+    (void)inv_delta;
     {   // np.minimum(np.maximum(s, 0), 1): NaN propagates
         double sc = fmin(fmax(s, 0.0), 1.0);
         s = (s != s) ? s : sc;
@@ -151,8 +201,8 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
         // Lt = log(v/m^2 + 1)   (utilities.py:10-19 restructured: one log, one sqrt, one exp)
         const double var = P.sigma * (1.0 - s);
         const double t = var * invm2 + 1.0;
-        const double Lt = log(t);
-        const double sig = sqrt(Lt);
+        const double Lt = log_ge1(t);
+        const double sig = sqrt_pos(Lt);
         kb = exp(logm - 0.5 * Lt + sig * rnd);
         kb = noisec < 0.0 ? P.sat_soil : kb;   // cell in no layer: vrettas_fung.py:143
         const double sl = SPECIAL ? s : pow(s, P.lambda);
@@ -229,7 +279,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         dym[c] = dy;
         const int slot = c * WAVE + lane;
         double kb, pf;
-        model_cell<SPECIAL>(P, psi, tab[T_POR * SLOTS + slot], tab[T_LOGM * SLOTS + slot],
+        model_cell<SPECIAL>(P, psi, tab[T_POR * SLOTS + slot], tab[T_INVDELTA * SLOTS + slot], tab[T_LOGM * SLOTS + slot],
                             tab[T_INVM2 * SLOTS + slot], tab[T_NOISEC * SLOTS + slot], rnd[c], th[c],
                             Kc[c], Cc[c], kb, pf);
         fl[c] = Kc[c] * (dy - 1.0);
@@ -256,18 +306,18 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     }
     // ---- evapo-transpiration (daylight only), richards_pde.py:258-302 + tree_roots.py:213-291
     if (P.flag_et && normal_mode && R.daylight) {
-        // (a) interior call: midpoints 1..n_root_int, normalised together
+        // (a) interior call: midpoints 1..n_root_int, normalised together.
+        // alpha_02 (tree_roots.py:245-265) is exactly 1 where theta > field capacity and 0 elsewhere:
+        // inside (wlt, fc] the reference's (theta - fc)/(fc - wlt) is <= 0 and gets clipped to 0.
         if (P.n_root_int > 0) {
             bool isr[CPL];
-            double wl[CPL], fcv[CPL], pre[CPL];
+            double pre[CPL];
             double s_w = 0.0, s_t = 0.0;
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
                 const int i = lane * CPL + c;
                 isr[c] = (i >= 1) && (i <= P.n_root_int);
-                wl[c] = tab[T_WLT * SLOTS + c * WAVE + lane];
-                fcv[c] = tab[T_FC * SLOTS + c * WAVE + lane];
-                s_w += isr[c] ? th[c] - wl[c] : 0.0;
+                s_w += isr[c] ? th[c] - tab[T_WLT * SLOTS + c * WAVE + lane] : 0.0;
                 s_t += isr[c] ? th[c] : 0.0;
                 pre[c] = s_t;
             }
@@ -280,39 +330,30 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                 const double excl = wave_excl_scan(lane_tot, lane);
                 double total = tot_theta * P.dz;
                 total = total == 0.0 ? 1.0 : total;
-                double a2[CPL];
+                const double inv_total = 1.0 / total;
+                bool a2[CPL];
                 bool all_one = true;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
-                    double v = 0.0;
-                    if (wl[c] < th[c] && th[c] <= fcv[c]) {
-                        double d2 = fcv[c] - wl[c];
-                        d2 = d2 == 0.0 ? 1.0 : d2;
-                        v = (th[c] - fcv[c]) / d2;
-                    }
-                    v = th[c] > fcv[c] ? 1.0 : v;
-                    v = fmin(fmax(v, 0.0), 1.0);
-                    a2[c] = v;
-                    all_one = all_one && (!isr[c] || v == 1.0);
+                    a2[c] = th[c] > tab[T_FC * SLOTS + c * WAVE + lane];
+                    all_one = all_one && (!isr[c] || a2[c]);
                 }
-                const bool wave_all_one = __all(all_one);
+                const double a2v = __all(all_one) ? 0.1 : 1.0;   // "roots drowning" guard, :270-272
                 double s_r = 0.0;
                 double rho[CPL];
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
-                    double d1 = tab[T_POR * SLOTS + c * WAVE + lane] - wl[c];
-                    d1 = d1 == 0.0 ? 1.0 : d1;
                     const double local = (excl + pre[c]) * P.dz;
-                    const double a1 = fmax(th[c] / d1, local / total);
-                    const double v = wave_all_one ? a2[c] * 0.1 : a2[c];
-                    rho[c] = isr[c] ? fabs(a1 * v) : 0.0;
+                    const double a1 = fmax(th[c] * tab[T_INVD1 * SLOTS + c * WAVE + lane], local * inv_total);
+                    rho[c] = (isr[c] && a2[c]) ? fabs(a1 * a2v) : 0.0;
                     s_r += rho[c];
                 }
                 double tot = wave_sum(s_r) * P.dz;
                 tot = tot == 0.0 ? 1.0 : tot;
+                const double inv_tot = 1.0 / tot;
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
-                    x_out[c] = (rho[c] / tot) * tab[T_ROOT * SLOTS + c * WAVE + lane];
+                    x_out[c] = (rho[c] * inv_tot) * tab[T_ROOT * SLOTS + c * WAVE + lane];
             } else {
                 water_k = 0.0;
 #pragma unroll
@@ -323,10 +364,11 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             for (int c = 0; c < CPL; c++) s_x += isr[c] ? x_out[c] : 0.0;
             double tot_x = wave_sum(s_x) * P.dz;
             if (tot_x > 1.0) {
+                const double inv_tx = 1.0 / tot_x;
                 s_x = 0.0;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
-                    x_out[c] = x_out[c] / tot_x;
+                    x_out[c] = x_out[c] * inv_tx;
                     s_x += isr[c] ? x_out[c] : 0.0;
                 }
                 tot_x = wave_sum(s_x) * P.dz;
@@ -345,18 +387,8 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             if (water_k > 0.0) {
                 const double local = t0 * P.dz;
                 const double total = local == 0.0 ? 1.0 : local;
-                double d1 = tab[T_POR * SLOTS + lane] - w0;
-                d1 = d1 == 0.0 ? 1.0 : d1;
-                const double a1 = fmax(t0 / d1, local / total);
-                double v = 0.0;
-                if (w0 < t0 && t0 <= f0) {
-                    double d2 = f0 - w0;
-                    d2 = d2 == 0.0 ? 1.0 : d2;
-                    v = (t0 - f0) / d2;
-                }
-                v = t0 > f0 ? 1.0 : v;
-                v = fmin(fmax(v, 0.0), 1.0);
-                v = v == 1.0 ? v * 0.1 : v;
+                const double a1 = fmax(t0 * tab[T_INVD1 * SLOTS + lane], local / total);
+                const double v = t0 > f0 ? 0.1 : 0.0;        // single cell: all-ones guard always applies
                 double rho = fabs(a1 * v);
                 double tot = rho * P.dz;
                 tot = tot == 0.0 ? 1.0 : tot;

@@ -63,15 +63,15 @@ __device__ __forceinline__ double gamma_k(int k) { return GAMMA_TAB[k]; }
 __device__ __forceinline__ double alpha_k(int k) { return ALPHA_TAB[k]; }
 __device__ __forceinline__ double error_const_k(int k) { return ERRC_TAB[k]; }
 
-// RMS norm of x[c]/s[c] over the D valid nodes
+// RMS norm of x[c]/scale[c] over the D valid nodes; is[c] = 1/scale[c]
 template <int CPL>
-__device__ __forceinline__ double rms_ratio(const double (&x)[CPL], const double (&s)[CPL], int lane, int D,
+__device__ __forceinline__ double rms_ratio(const double (&x)[CPL], const double (&is)[CPL], int lane, int D,
                                             double inv_sqrt_d)
 {
     double acc = 0.0;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
-        const double r = x[c] / s[c];
+        const double r = x[c] * is[c];
         acc += (lane * CPL + c < D) ? r * r : 0.0;
     }
     return sqrt(wave_sum(acc)) * inv_sqrt_d;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * z;
                 }
                 // ================= one BDF integration over [t0, tf] =================
-                double ycur[CPL], f[CPL], yp[CPL], psiv[CPL], scl[CPL], dd[CPL];
+                double ycur[CPL], f[CPL], yp[CPL], psiv[CPL], scl[CPL] /* 1/scale */, dd[CPL];
                 double jl[CPL], jd[CPL], ju[CPL], hj[CPL];
                 TriLU<CPL> F;
                 double t = t0, h_abs = 0.0, h0 = 0.0, t_new = t0, cc = 0.0, min_step = 0.0;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             y0v[c] = ycur[c];
                             Dv[1 * SLOTS + slot] = f[c];      // parked here until h_abs is known
                             V[V_FP * SLOTS + slot] = f[c];    // base f of the first Jacobian
-                            scl[c] = ATOL + fabs(y0v[c]) * RTOL;
+                            scl[c] = 1.0 / (ATOL + fabs(y0v[c]) * RTOL);
                         }
                         const double d0 = rms_ratio<CPL>(y0v, scl, lane, D, inv_sqrt_d);
                         const double d1 = rms_ratio<CPL>(f, scl, lane, D, inv_sqrt_d);
@@ -524,6 +524,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             }
                             const double h = t_new - t;
                             h_abs = fabs(h);
+                            const double inv_alpha = 1.0 / alpha_k(order);
 #pragma unroll
                             for (int c = 0; c < CPL; c++) {
                                 const int slot = c * WAVE + lane;
@@ -534,8 +535,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                                     p += dk * gamma_k(k);
                                 }
                                 yp[c] = s;
-                                scl[c] = ATOL + RTOL * fabs(s);
-                                psiv[c] = p / alpha_k(order);
+                                scl[c] = 1.0 / (ATOL + RTOL * fabs(s));
+                                psiv[c] = p * inv_alpha;
                             }
                             cc = h / alpha_k(order);
                             phase = C_NEWTON_BEGIN;
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         double e[CPL];
 #pragma unroll
                         for (int c = 0; c < CPL; c++) {
-                            scl[c] = ATOL + RTOL * fabs(ycur[c]);
+                            scl[c] = 1.0 / (ATOL + RTOL * fabs(ycur[c]));
                             e[c] = ec * dd[c];
                         }
                         error_norm = rms_ratio<CPL>(e, scl, lane, D, inv_sqrt_d);

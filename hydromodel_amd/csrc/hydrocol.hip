@@ -218,9 +218,9 @@ __global__ void model_nodes_kernel(const StepArgs A, const double *node_tabs, in
         z = philox_normal(A.seed, (unsigned long long)(A.member_offset + member), 0u, (unsigned)i) * A.nscale[member];
     double th, K, C, kb, pf;
     if (special)
-        model_cell<true>(P, A.psi[k], por, log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
+        model_cell<true>(P, A.psi[k], por, 1.0 / (por - P.theta_res), log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
     else
-        model_cell<false>(P, A.psi[k], por, log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
+        model_cell<false>(P, A.psi[k], por, 1.0 / (por - P.theta_res), log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
     out[k] = th;
     out[total + k] = K;
     out[2 * total + k] = C;
@@ -404,6 +404,9 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
         tab[(size_t)T_LOGM * S + slot] = std::log(mk);
         tab[(size_t)T_INVM2 * S + slot] = 1.0 / (mk * mk);
         tab[(size_t)T_NOISEC * S + slot] = noisec;
+        tab[(size_t)T_INVDELTA * S + slot] = 1.0 / (por - p->theta_res);
+        const double d1 = por - wlt;                       // tree_roots.py:235-238
+        tab[(size_t)T_INVD1 * S + slot] = 1.0 / (d1 == 0.0 ? 1.0 : d1);
     };
     for (int lane = 0; lane < WAVE; lane++)
         for (int c = 0; c < cpl; c++) {
