@@ -1,0 +1,110 @@
+"""Command line of the reference (``/root/reference/code/berkeley_hydro_main.py``), GPU-backed.
+
+    python3 berkeley_hydro_main.py --params P.json [--data D.csv] [--seed S] [--device K]
+
+Same 12 required JSON keys (:40-43), same header-less 4-column CSV (:115-116), same messages and
+exit codes (any error -> message + exit status 1, :138-142).  Additions (the reference tolerates
+unknown keys, only membership of the 12 is checked):
+
+* ``--seed`` / JSON ``"Seed"``: seeds ``Simulation(name, seed)``; the reference's CLI cannot be seeded.
+* JSON ``"Ensemble": {"Members": N, "Seed": s, "Days": d}``: run N stochastic members with in-kernel
+  Philox noise and write the per-row water-table mean / sigma to ``<Output_Name>_ensemble.npz``.
+"""
+import sys
+from pathlib import Path
+
+REQUIRED_KEYS = ("Trees", "Well_No", "Output_Name", "IC_Filename",
+                 "Data_Filename", "Water_Content", "Environmental",
+                 "Soil_Properties", "Site_Information", "Simulation_Flags",
+                 "Hydrological_Model", "Hydraulic_Conductivity")
+
+
+def validateInputParametersFile(filename):
+    """berkeley_hydro_main.py:13-61: key membership only, values are not validated here."""
+    import json
+    with open(filename, "r") as input_file:
+        model_params = json.load(input_file)
+        for k in REQUIRED_KEYS:
+            if k not in model_params:
+                raise ValueError(f" Key: {k}, is not given.")
+        print(" Model parameters are given correctly.")
+    return model_params
+
+
+def main(params_file=None, data_file=None, seed=None, device=0):
+    """berkeley_hydro_main.py:65-145."""
+    import pandas as pd
+    if params_file is not None:
+        try:
+            params_file = Path(params_file)
+            params = validateInputParametersFile(params_file)
+        except ValueError as e0:
+            print(e0)
+            sys.exit(1)
+    else:
+        print(" The simulation can't run without input parameters.")
+        sys.exit(1)
+    data_file = Path(data_file) if data_file is not None else Path(params["Data_Filename"])
+    print(f" Simulation water data file: {data_file}")
+    try:
+        with open(data_file, "r") as input_file:
+            water_data = pd.read_csv(input_file, names=["ID", "Datenum", "Precipitation_cm", "WTD_m"])
+        output_name = params["Output_Name"]
+        if output_name is None:
+            output_name = "Sim_01"
+        if seed is None:
+            seed = params.get("Seed")
+        ens = params.get("Ensemble")
+        if ens:
+            _run_ensemble(params, water_data, output_name, ens, device)
+        else:
+            from .simulation import Simulation
+            sim_01 = Simulation(output_name, seed=seed, device=device)
+            sim_01.setupModel(params, water_data)
+            sim_01.run()
+            sim_01.saveResults()
+    except Exception as e1:  # noqa: BLE001 - the reference converts every failure to exit status 1
+        print(e1)
+        sys.exit(1)
+
+
+def _run_ensemble(params, water_data, output_name, ens, device):
+    import numpy as np
+    from .digest import ColumnTables, ForcingDigest, load_site_well
+    from .ensemble import EnsembleSimulation
+    cols = ColumnTables(params, load_site_well(params))
+    forcing = ForcingDigest(params, water_data, cols)
+    n_members = int(ens.get("Members", 4096))
+    days = int(ens.get("Days", (forcing.dim_t - 1) // 48))
+    rows = min(days * 48, forcing.dim_t - 1)
+    sim = EnsembleSimulation(cols, forcing, n_members, seed=int(ens.get("Seed", 0)), device=device)
+    done = 0
+    while done < rows:
+        n = min(48 * 30, rows - done)
+        sim.advance(n)
+        done += n
+        print(f" [Ensemble x{n_members}] {done} rows done")
+    moments = sim.moments()
+    mean_cm, std_cm = sim.wtd_mean_std(moments)
+    out = Path(output_name.strip().replace(" ", "_") + "_ensemble.npz")
+    np.savez_compressed(out, moments=moments, wtd_mean_cm=mean_cm, wtd_std_cm=std_cm, rows=np.array(rows),
+                        members=np.array(n_members), initial_cond=sim.psi0)
+    print(f" Saving the ensemble water-table statistics to: {out}")
+    sim.close()
+
+
+def run_cli(argv=None):
+    """berkeley_hydro_main.py:149-177."""
+    argv = sys.argv if argv is None else argv
+    if len(argv) > 1:
+        import argparse
+        parser = argparse.ArgumentParser(description=" Berkeley Hydrological Simulation ")
+        parser.add_argument("--params", help=" Input file (.json) with simulation parameters.")
+        parser.add_argument("--data", help=" Input file (.csv) with simulation data (e.g.: precipitation, wtd).")
+        parser.add_argument("--seed", type=int, default=None, help=" Seed of the noise stream (reproducible runs).")
+        parser.add_argument("--device", type=int, default=0, help=" GPU ordinal.")
+        args = parser.parse_args(argv[1:])
+        main(args.params, args.data, args.seed, args.device)
+        print(' Simulation completed.')
+    else:
+        sys.exit('Error: Not enough input parameters.')

@@ -56,7 +56,7 @@ def write_forcing_csv(path, n_years=1, seed=123, wtd_m=-3.00):
     ids, datenum, precip, wtd = synthetic_forcing(n_years, seed, wtd_m)
     with open(path, "w") as fh:
         for i in range(ids.size):
-            fh.write(f"{ids[i]:d},{datenum[i]!r},{precip[i]!r},{wtd[i]!r}\n")
+            fh.write(f"{int(ids[i]):d},{float(datenum[i])!r},{float(precip[i])!r},{float(wtd[i])!r}\n")
     return Path(path)
 
 

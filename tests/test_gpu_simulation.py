@@ -1,0 +1,100 @@
+"""Config 1: the reference's single-column workflow (Simulation / CLI) with the loop on the GPU."""
+import json
+
+import numpy as np
+import pytest
+
+from helpers import WELLS, forcing_frame, golden
+from hydromodel_amd.synthetic import default_parameters, write_forcing_csv, write_site_information
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def year_run(tmp_path_factory):
+    import __graft_entry__ as ge
+    ge.build()
+    from hydromodel_amd.simulation import Simulation
+    tmp = tmp_path_factory.mktemp("sim")
+    params = default_parameters()
+    params["Site_Information"] = str(write_site_information(tmp / "site.json", {1: WELLS[1]}))
+    params["Well_No"] = 1
+    sim = Simulation("golden_1", seed=911)
+    sim.setupModel(params, forcing_frame(1))
+    sim.run()
+    return sim
+
+
+def test_output_dictionary_has_the_reference_layout(year_run):
+    out = year_run.output
+    T, D = 17520, 101
+    assert sorted(out) == sorted(["K_hrc", "K_bkg", "S_eff", "psi_press", "theta_vol", "abs_error",
+                                  "wtd_est_cm", "lateral_flow", "transpiration"])
+    for k in ("K_hrc", "K_bkg", "S_eff", "psi_press", "theta_vol"):
+        assert out[k].shape == (T, D) and np.isfinite(out[k]).all()
+    assert out["abs_error"].shape == out["wtd_est_cm"].shape == (T,)
+    assert out["lateral_flow"].shape == out["transpiration"].shape == (T - 1,)
+    assert np.all(out["S_eff"] <= 1.0 + 1e-12) and np.all(out["S_eff"] > 0.0)
+    assert np.all(out["K_hrc"] <= out["K_bkg"] * (1 + 1e-15))
+
+
+def test_year_long_run_tracks_the_reference(year_run):
+    g = golden("g5_traj_1.npz")
+    out = year_run.output
+    assert np.max(np.abs(year_run.mData["initial_cond"] - g["initial_cond"])) < 0.02     # spin-up, ~115 solves
+    # first rows: still on the reference trajectory (the IC differs by ~1e-3 cm after the chaotic spin-up)
+    d = np.abs(out["psi_press"][1] - g["rec_y1"][0])
+    assert d.max() < 0.02
+    ref_idx = np.rint(g["wtd_est_cm"] / 5.0).astype(int)
+    idx = np.rint(out["wtd_est_cm"] / 5.0).astype(int)
+    diff = np.abs(idx - ref_idx)
+    # Never more than one 5-cm cell away over 17 520 rows.  Exact equality is a weaker statement: the
+    # handful of rows on which the solver gives up (x0.8 noise damping, richards_pde.py:522) fall on
+    # different rows in every implementation -- the event is chaotic in the last bits -- and each one
+    # rescales the base noise for the rest of the year (measured: reference 14, C oracle 10, GPU 11 such
+    # rows; DESIGN.md "Parity tiers").  The first two months, before the first such event, agree closely.
+    assert diff.max() <= 1
+    assert (diff[:2900] == 0).mean() > 0.95
+    assert (diff == 0).mean() > 0.60
+    assert abs(out["abs_error"].mean() - g["abs_error"].mean()) < 1.0
+    # daily theta profile statistics agree (noise-free diagnostic)
+    keep = g["daily_rows"]
+    assert np.abs(out["theta_vol"][keep] - g["theta_daily"]).mean() < 2e-3
+
+
+def test_cli_end_to_end(tmp_path, monkeypatch, capsys):
+    import __graft_entry__ as ge
+    ge.build()
+    from hydromodel_amd import cli
+    from hydromodel_amd.simulation import loadResults
+    params = default_parameters()
+    params["Site_Information"] = str(write_site_information(tmp_path / "site.json", {10: WELLS[1]}))
+    params["Data_Filename"] = str(write_forcing_csv(tmp_path / "forcing.csv", 1))
+    params["Output_Name"] = "Sim 00"
+    (tmp_path / "p.json").write_text(json.dumps(params))
+    monkeypatch.chdir(tmp_path)
+    cli.run_cli(["berkeley_hydro_main.py", "--params", str(tmp_path / "p.json"), "--seed", "5"])
+    text = capsys.readouterr().out
+    for msg in (" Model parameters are given correctly.", " Selected model: Vrettas-Fung",
+                "Burn in period started", "finished at [itr:", " [Well No. 10] 100: MAE =", " Elapsed time:",
+                " Simulation completed."):
+        assert msg in text, msg
+    files = list(tmp_path.glob("Sim_00.*"))
+    assert len(files) == 1
+    data = loadResults(files[0])
+    assert data["psi_press"].shape == (17520, 101)
+
+
+def test_cli_ensemble_block(tmp_path, monkeypatch, capsys):
+    from hydromodel_amd import cli
+    params = default_parameters()
+    params["Site_Information"] = str(write_site_information(tmp_path / "site.json", {10: WELLS[200]}))
+    params["Data_Filename"] = str(write_forcing_csv(tmp_path / "forcing.csv", 1))
+    params["Ensemble"] = {"Members": 256, "Seed": 3, "Days": 2}
+    (tmp_path / "p.json").write_text(json.dumps(params))
+    monkeypatch.chdir(tmp_path)
+    cli.run_cli(["berkeley_hydro_main.py", "--params", str(tmp_path / "p.json")])
+    data = np.load(tmp_path / "Sim_00_ensemble.npz")
+    assert int(data["members"]) == 256 and int(data["rows"]) == 96
+    assert np.array_equal(data["moments"][0, 1:97], np.full(96, 256))
+    assert np.all(np.isfinite(data["wtd_mean_cm"][1:97]))
