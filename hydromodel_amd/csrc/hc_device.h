@@ -108,8 +108,32 @@ __device__ __forceinline__ double shfl_down1(double v, int lane, double fill)
     return dpp_d<DPP_WAVE_SHL1>(v, fill);
 }
 
-// log(x) for finite x >= 1 (argument of the log-normal transform): fdlibm's e_log kernel,
-// < 1 ulp, without the special-case ladder of the library routine
+// d = a*b + c with the addend in an SGPR pair.  hipcc otherwise turns every Horner step with a 64-bit
+// literal into two v_mov_b32 plus v_fmac_f64; gfx950 VOP3 cannot encode a 64-bit literal, but it can read
+// one SGPR pair, and two s_mov_b32 are SALU work.  Pure VALU instruction: no wait-state obligations.
+__device__ __forceinline__ double fma_s(double a, double b, double c_uniform)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+}
+
+// a/b to ~1 ulp without the IEEE scale/fixup ladder (operands far from the exponent limits)
+__device__ __forceinline__ double fast_div(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double fast_rcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return fma(fma(-b, r, 1.0), r, r);
+}
+// log(x) for finite x >= 1 (argument of the log-normal transform): fdlibm's e_log kernel, ~1 ulp
 __device__ __forceinline__ double log_ge1(double x)
 {
     double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
@@ -118,15 +142,36 @@ __device__ __forceinline__ double log_ge1(double x)
     m = lo ? m + m : m;
     e = lo ? e - 1 : e;
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    const double s = fast_div(f, 2.0 + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-    const double t2 = z * (6.666666666666735130e-01 +
-                           w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double t1 = w * fma_s(w, fma_s(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma_s(w, fma_s(w, fma_s(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                         2.857142874366239149e-01), 6.666666666666735130e-01);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+// exp(x) for |x| < 700 (no overflow / underflow ladder): x = k ln2 + r, Taylor to r^13 (< 1e-17 rel)
+__device__ __forceinline__ double exp_mid(double x)
+{
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = fma_s(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
+    p = fma_s(p, r, 1.0 / 39916800.0);
+    p = fma_s(p, r, 1.0 / 3628800.0);
+    p = fma_s(p, r, 1.0 / 362880.0);
+    p = fma_s(p, r, 1.0 / 40320.0);
+    p = fma_s(p, r, 1.0 / 5040.0);
+    p = fma_s(p, r, 1.0 / 720.0);
+    p = fma_s(p, r, 1.0 / 120.0);
+    p = fma_s(p, r, 1.0 / 24.0);
+    p = fma_s(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
 }
 // sqrt(x) for 0 <= x < ~1e300, no denormal scaling (Newton on v_rsq_f64, two residual corrections)
 __device__ __forceinline__ double sqrt_pos(double x)
@@ -141,6 +186,13 @@ __device__ __forceinline__ double sqrt_pos(double x)
     d = fma(-g, g, x);
     g = fma(d, h, g);
     return x == 0.0 ? 0.0 : g;
+}
+// 1/sqrt(x) for 1 <= x < 1e300 (x = 1 + (alpha psi)^2)
+__device__ __forceinline__ double rsqrt_ge1(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
 }
 
 // ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
@@ -181,40 +233,37 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
                                            double logm, double invm2, double noisec, double rnd,
                                            double &theta, double &K, double &C, double &kb, double &pfac)
 {
+    (void)inv_delta;
     const double delta = por - P.theta_res;
     const bool sat = psi >= P.psi_sat;
     const double ap = P.alpha * fabs(psi);
     if (SPECIAL)
-        pfac = rsqrt(1.0 + ap * ap);
+        pfac = rsqrt_ge1(fma(ap, ap, 1.0));
     else
         pfac = pow(1.0 + pow(ap, P.n), -P.m);
-    double q = P.theta_res + delta * pfac;
+    double q = fma(delta, pfac, P.theta_res);
     q = sat ? por : q;
-    double s = (q - P.theta_res) / delta;   // a true division: 1 - s is ill-conditioned near saturation
-    (void)inv_delta;
-    {   // np.minimum(np.maximum(s, 0), 1): NaN propagates
-        double sc = fmin(fmax(s, 0.0), 1.0);
-        s = (s != s) ? s : sc;
-    }
+    // a true division: 1 - s is ill-conditioned near saturation, a 1-ulp reciprocal shows up in K_bkg
+    double s = (q - P.theta_res) / delta;
+    s = fmin(fmax(s, 0.0), 1.0);
     if (SPECIAL || P.model == 0) {
         // K_bkg = exp(log(m^2/sqrt(v+m^2)) + sqrt(log(v/m^2+1))*rnd)  ==  exp(log m - Lt/2 + sqrt(Lt)*rnd),
         // Lt = log(v/m^2 + 1)   (utilities.py:10-19 restructured: one log, one sqrt, one exp)
         const double var = P.sigma * (1.0 - s);
-        const double t = var * invm2 + 1.0;
+        const double t = fma(var, invm2, 1.0);
         const double Lt = log_ge1(t);
         const double sig = sqrt_pos(Lt);
-        kb = exp(logm - 0.5 * Lt + sig * rnd);
+        kb = exp_mid(fma(sig, rnd, fma(-0.5, Lt, logm)));
         kb = noisec < 0.0 ? P.sat_soil : kb;   // cell in no layer: vrettas_fung.py:143
         const double sl = SPECIAL ? s : pow(s, P.lambda);
-        K = sl * kb;
+        K = sl * kb;                            // <= kb because 0 <= sl <= 1: np.minimum(K, kbkg) is a no-op
     } else {
         // vanGenuchten.py:91-98
         kb = P.sat_soil;
         const double mth = pow(s, P.inv_m);
-        K = kb * sqrt(s) * pow(1.0 - pow(1.0 - mth, P.m), P.n);
+        K = fmin(kb * sqrt(s) * pow(1.0 - pow(1.0 - mth, P.m), P.n), kb);
     }
     K = sat ? kb : K;
-    K = (K != K) ? K : fmin(K, kb);
     double s3, apn;
     if (SPECIAL) {
         s3 = s * s * s;
@@ -224,8 +273,8 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
         apn = pow(ap, P.n - 1.0);
     }
     double c = P.mn_alpha * delta * s3 * apn;
-    c = sat ? P.epsilon : c;
-    c = (c < P.epsilon || !isfinite(c)) ? P.epsilon : c;
+    // saturated, below epsilon, NaN or infinite -> epsilon (vrettas_fung.py:243-249)
+    c = (!sat && c >= P.epsilon && c < INFINITY) ? c : P.epsilon;
     theta = q;
     C = c;
 }
@@ -440,29 +489,29 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         }
         pL = readlane_d(p, WAVE - 1);
     }
-    // ---- assemble dy/dt, richards_pde.py:108-156
+    // ---- assemble dy/dt, richards_pde.py:108-156.  One formula for every node:
+    //   dy/dt_i = (f_i - f_{i-1} + h (s_i + s_{i-1})) / (h (c_i + c_{i-1})),   h = dz/2,
+    // with (c, s, f)_{-1} = (0, 0, -pL) at the top and (c, s, f)_{D-1} = 0 at the bottom, which is
+    // :119 and :155 after cancelling the signs; padding nodes come out as 0/1 = 0.
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const bool vmid = lane * CPL + c < D - 1;
+        Cc[c] = vmid ? Cc[c] : 0.0;
+        fl[c] = vmid ? fl[c] : 0.0;
+    }
     const double cP0 = shfl_up1(Cc[CPL - 1], lane, 0.0);
     const double sP0 = shfl_up1(sk[CPL - 1], lane, 0.0);
-    const double fP0 = shfl_up1(fl[CPL - 1], lane, 0.0);
+    const double fP0 = shfl_up1(fl[CPL - 1], lane, -pL);
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const int i = lane * CPL + c;
         const double cP = c == 0 ? cP0 : Cc[c > 0 ? c - 1 : 0];
         const double sP = c == 0 ? sP0 : sk[c > 0 ? c - 1 : 0];
         const double fP = c == 0 ? fP0 : fl[c > 0 ? c - 1 : 0];
-        double num, den;
-        if (i == 0) {
-            den = half * Cc[c];
-            num = pL + (fl[c] + half * sk[c]);
-        } else if (i < D - 1) {
-            den = half * Cc[c] + half * cP;
-            num = fl[c] - fP + (half * sk[c] + half * sP);
-        } else {
-            den = -half * cP;
-            num = fP - half * sP;
-        }
+        double den = half * Cc[c] + half * cP;
+        const double num = (fl[c] - fP) + (half * sk[c] + half * sP);
         den = den == 0.0 ? 1.0 : den;
-        f[c] = i < D ? num / den : 0.0;
+        f[c] = fast_div(num, den);
         if (aux && i < D - 1) {
             aux[i] = Cc[c];
             aux[(D - 1) + i] = sk[c];

@@ -31,7 +31,8 @@ constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 
 // per-wave LDS vectors (each 64*CPL doubles)
 enum { V_Y = 0, V_FP, V_NZ, V_FAC, V_D0, NVEC = V_D0 + MAX_ORDER + 3 };
-constexpr int WAVE_SCRATCH = 128;   // doubles: RU matrices (3 x 36) + row-0 values of the FD groups
+constexpr int WAVE_SCRATCH = 128;
+constexpr int MAX_PHASE_ITERATIONS = 60000;    // > 10x the costliest attempt observed (1419 RHS evaluations in a row)
 
 struct StepArgs {
     ColumnDev P;
@@ -51,7 +52,7 @@ struct StepArgs {
     unsigned short *wtd_u16;  // [n_rows][N]
     int *stats;               // [n_rows][N][6] or null
     double *psi_rows;         // [n_rows][N][D] or null
-    unsigned long long *counters;   // [0] FD-Jacobian redo events (unsupported path), [1] failed attempts
+    unsigned long long *counters;   // [0] FD-Jacobian redo events (unsupported path), [1] failed attempts, [2] loop-guard trips
 };
 
 // gamma = [0, cumsum(1/k)], alpha = (1 - kappa) * gamma, error_const = kappa * gamma + 1/(k+1)
@@ -340,8 +341,13 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 }
                 int phase = PH_F0;
                 bool need_rhs = true;
+                int guard = 0;                       // every wave must reach an exit: bound the phase loop
                 for (;;) {
-                    if (need_rhs) rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr);
+                    if (++guard > MAX_PHASE_ITERATIONS) {
+                        if (lane == 0) atomicAdd(&A.counters[2], 1ull);
+                        phase = C_FAIL;
+                    }
+                    if (need_rhs && phase < C_SUCCESS) rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr);
                     need_rhs = true;
                     if (phase == PH_F0) {
                         // BDF.__init__: f0 = fun(t0, y0); select_initial_step part 1
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                                 double fac = V[V_FAC * SLOTS + slot];
                                 const double ysc = (fb >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
                                 double h = (yp[c] + fac * ysc) - yp[c];
-                                while (vnode[c] && h == 0.0) {
+                                for (int it = 0; it < 64 && vnode[c] && h == 0.0; it++) {
                                     fac *= 10.0;
                                     h = (yp[c] + fac * ysc) - yp[c];
                                 }

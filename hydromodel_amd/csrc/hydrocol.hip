@@ -270,15 +270,22 @@ int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, d
     return HC_OK;
 }
 
+// waves per workgroup per CPL: as many as the 160 KB of LDS admit (tables + per-wave vectors)
 #define HC_DISPATCH(FN, ...)                                                            \
     switch (h->cpl) {                                                                   \
         case 2: return h->special ? FN<2, true, 4>(__VA_ARGS__) : FN<2, false, 4>(__VA_ARGS__); \
         case 3: return h->special ? FN<3, true, 4>(__VA_ARGS__) : FN<3, false, 4>(__VA_ARGS__); \
         case 4: return h->special ? FN<4, true, 4>(__VA_ARGS__) : FN<4, false, 4>(__VA_ARGS__); \
         case 5: return h->special ? FN<5, true, 4>(__VA_ARGS__) : FN<5, false, 4>(__VA_ARGS__); \
+        case 6: return h->special ? FN<6, true, 3>(__VA_ARGS__) : FN<6, false, 3>(__VA_ARGS__); \
+        case 7: return h->special ? FN<7, true, 2>(__VA_ARGS__) : FN<7, false, 2>(__VA_ARGS__); \
+        case 8: return h->special ? FN<8, true, 2>(__VA_ARGS__) : FN<8, false, 2>(__VA_ARGS__); \
+        case 9: return h->special ? FN<9, true, 1>(__VA_ARGS__) : FN<9, false, 1>(__VA_ARGS__); \
+        case 10: return h->special ? FN<10, true, 1>(__VA_ARGS__) : FN<10, false, 1>(__VA_ARGS__); \
         default: break;                                                                 \
     }                                                                                   \
-    return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= 320", h->p.dim_d, h->cpl)
+    return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= %d", h->p.dim_d, h->cpl, \
+                HC_MAX_DEPTH_NODES)
 
 int launch_step(hc_handle *h, const StepArgs &A) { HC_DISPATCH(launch_step_t, h, A); }
 int launch_rhs(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
@@ -640,6 +647,9 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
     }
     unsigned long long cnt[4];
     HIP_TRY(hipMemcpy(cnt, h->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+    if (cnt[2] != 0)
+        return fail(HC_ERR_DEVICE, "%llu BDF attempts hit the kernel's iteration guard (non-terminating step control)",
+                    cnt[2]);
     if (cnt[0] != 0)
         return fail(HC_ERR_UNSUPPORTED,
                     "%llu FD-Jacobian evaluations hit num_jac's retry-with-larger-step branch, which this build "

@@ -247,11 +247,17 @@ def test_retry_rule_damps_base_noise_in_place(gpu):
         out = st.step_rows(int(i), 1, fresh_noise=np.zeros((0,)), want_stats=True)
         att = int(out["stats"][0, 0, 4])
         base_after = st.get_noise_base()[0]
-        if att == so["attempts"]:
-            assert np.array_equal(base_after, n_out)
-            checked += 1
-        fails = att - 1 if att < 5 or np.isfinite(st.get_state()).all() else att
-        assert att >= 1 and fails >= 0
+        # every failed attempt multiplies the base vector by 0.8 in place; the last attempt may or may
+        # not have succeeded (a row that exhausts its 5 attempts is damped 5 times)
+        cands = []
+        v = nin.copy()
+        for k in range(att + 1):
+            if k >= att - 1:
+                cands.append(v.copy())
+            v = v * 0.8
+        assert att >= 2 or att == so["attempts"]
+        assert any(np.array_equal(base_after, c) for c in cands), (i, att)
+        checked += 1
     assert checked >= 3
     st.close()
 
@@ -419,13 +425,48 @@ def test_error_paths(gpu):
         st.step_rows(48, 1)                     # a refresh row in host-noise mode needs the vectors
     st.close()
     params = default_parameters()
-    big = ColumnTables(params, synthetic_well(401))
+    big = ColumnTables(params, synthetic_well(701))          # deeper than any reference well (max D = 581)
     fb = ForcingDigest(params, forcing_frame(1), big)
-    st = gpu.EnsembleStepper(big, fb, 1)
-    st.set_state(big.z - 300.0)
-    st.set_noise_philox(1, 0)
-    with pytest.raises(HcError, match="D <= 320"):
-        st.step_rows(1, 1)
-    st.close()
+    with pytest.raises(HcError, match="dim_d"):
+        gpu.EnsembleStepper(big, fb, 1)
     with pytest.raises(TypeError):
         gpu.EnsembleStepper(cols, forcing, 1, flags={"PREDICT": True})
+
+
+@pytest.mark.parametrize("dim_d", [361, 401, 461, 541, 581])
+def test_deep_reference_wells_match_oracle(gpu, dim_d):
+    """Wells 13, 10 (the reference's default), 5, 15, 14 of site_information.json: 6..10 cells per lane."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import pressure_head
+    from hydromodel_amd.synthetic import default_parameters, synthetic_well
+    from helpers import forcing_frame
+    params = default_parameters()
+    well = synthetic_well(dim_d)
+    well["sat_depth"] = 125.0 if dim_d == 401 else 100.0
+    cols = ColumnTables(params, well)
+    forcing = ForcingDigest(params, forcing_frame(1), cols)
+    o = _oracle(cols, forcing)
+    rng = np.random.default_rng(dim_d)
+    D, N = cols.dim_d, 3
+    Y = np.tile(cols.z - 300.0, (N, 1)) + 2.0 * rng.standard_normal((N, D))
+    base = rng.standard_normal((N, D))
+    st = gpu.EnsembleStepper(cols, forcing, N)
+    st.set_state(Y)
+    st.set_noise_host(base)
+    for row in (2, 24):
+        dydt, aux = st.rhs(row, want_aux=True)
+        for k in range(N):
+            ref, ra = o.rhs(_row(forcing, row), Y[k], base[k], want_aux=True)
+            assert rel_err(aux["f"][k], ra["f"]) < 1e-11
+            assert rel_err(aux["c"][k], ra["c"], 1e-7) < 1e-11
+            assert rel_err(dydt[k], ref) < 1e-7
+    rows = 30
+    nf = st.n_refresh(1, rows)
+    out = st.step_rows(1, rows, fresh_noise=np.zeros((nf, N, D)), want_wtd=True, want_stats=True)
+    y1 = st.get_state()
+    for k in range(N):
+        r = o.run(forcing, Y[k], base[k], np.zeros((max(nf, 1), D)), 1, 1 + rows, want_stats=True)
+        assert np.array_equal(out["wtd"][:, k], r["wtd_est"][1:1 + rows])
+        assert np.max(np.abs(y1[k] - r["psi"]) / (1 + np.abs(r["psi"]))) < 1e-3
+        assert (out["stats"][:, k, 0] == r["per_row"][1:1 + rows, 0]).mean() >= 0.7
+    st.close()
