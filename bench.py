@@ -33,6 +33,11 @@ sys.path.insert(0, str(REPO))
 
 ROWS_PER_DAY = 48
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# HBM bytes per member per 48-row launch at D=300, from rocprofv3 PMC passes on this launch shape
+# (profiles/r01_pmc_fetch_size.csv, r01_pmc_write_size.csv; N = 65 536): 2 x FETCH_SIZE (gfx950 counts
+# half of the fetched bytes -- confirmed on a calibration dispatch that only loads and stores psi)
+# + WRITE_SIZE = (2 x 78 574.5 + 178 688) KiB / 65 536 members.
+PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 = (2 * 78574.5 + 178688.0) * 1024.0 / 65536.0
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
 
 
@@ -155,7 +160,12 @@ def main():
                    "members_per_gpu": N, "depth_nodes": D, "rows_per_step": ROWS_PER_DAY,
                    "noise": "philox4x32-10 in-kernel", "parallelism": f"members sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": (PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 * N
+                                 if (D == 300 and abs(rows_per_launch - 48) < 1e-9) else None),
+                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same launch shape "
+                                       "(profiles/r01_pmc_*.csv), scaled by members; psi stays in LDS for the "
+                                       "48 rows of a launch, so HBM sees ~1/44 of the algorithmic bytes",
                      "kernel": "hc::step_kernel", "launch_ms": launch_ms, "launches": sim.launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "path is fp64-VALU/recurrence bound (SURVEY.md §8d): ~24 RHS evaluations per "

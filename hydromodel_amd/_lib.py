@@ -54,6 +54,7 @@ EXPORTS = {
     "hc_philox_normals": ([C.c_void_p, C.c_int64, C.c_int64, _dp], C.c_int),
     "hc_step_rows": ([C.c_void_p, C.POINTER(StepArgs)], C.c_int),
     "hc_synchronize": ([C.c_void_p], C.c_int),
+    "hc_get_counters": ([C.c_void_p, C.POINTER(C.c_uint64)], C.c_int),
     "hc_get_moments": ([C.c_void_p, _lp], C.c_int),
     "hc_set_moments": ([C.c_void_p, _lp], C.c_int),
     "hc_reset_moments": ([C.c_void_p], C.c_int),

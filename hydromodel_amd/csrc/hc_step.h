@@ -31,7 +31,7 @@ constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 
 // per-wave LDS vectors (each 64*CPL doubles)
 enum { V_Y = 0, V_FP, V_NZ, V_FAC, V_D0, NVEC = V_D0 + MAX_ORDER + 3 };
-constexpr int WAVE_SCRATCH = 128;
+constexpr int WAVE_SCRATCH = 160;
 constexpr int MAX_PHASE_ITERATIONS = 60000;    // > 10x the costliest attempt observed (1419 RHS evaluations in a row)
 
 struct StepArgs {
@@ -52,7 +52,8 @@ struct StepArgs {
     unsigned short *wtd_u16;  // [n_rows][N]
     int *stats;               // [n_rows][N][6] or null
     double *psi_rows;         // [n_rows][N][D] or null
-    unsigned long long *counters;   // [0] FD-Jacobian redo events (unsupported path), [1] failed attempts, [2] loop-guard trips
+    unsigned long long *counters;   // [0] FD-Jacobian passes that retried columns with a 10x step, [1] failed attempts, [2] loop-guard trips
+    double jac_reject;        // NUM_JAC_DIFF_REJECT = EPS**0.875 (debug override: HYDROCOL_DEBUG_JAC_REJECT)
 };
 
 // gamma = [0, cumsum(1/k)], alpha = (1 - kappa) * gamma, error_const = kappa * gamma + 1/(k+1)
@@ -226,8 +227,30 @@ __device__ __forceinline__ void lu_solve(const TriLU<CPL> &F, double (&x)[CPL], 
     for (int c = 0; c < CPL - 1; c++) x[c] = (x[c] - F.l[c] * xp - F.u[c] * xe) * F.ib[c];
 }
 
+// _sparse_num_jac bookkeeping for ONE column j: max |f_new - f| over the stored rows j-1, j, j+1
+// (first maximum in row order) and scale = max(|f|, |f_new|) at that row.  An all-zero column makes
+// scipy's sparse argmax return row 0 (scipy/sparse/_data.py, _arg_min_or_max_axis).
+__device__ __forceinline__ void col_stats(bool hasU, bool hasD, double fnU, double fbU, double fnM, double fbM,
+                                          double fnD, double fbD, double fn_row0, double fb_row0, double &md,
+                                          double &sc)
+{
+    const double dU = hasU ? fabs(fnU - fbU) : -1.0;
+    const double dM = fabs(fnM - fbM);
+    const double dD = hasD ? fabs(fnD - fbD) : -1.0;
+    double sf = fbU, sn = fnU;
+    md = dU;
+    if (!(dU >= dM)) { md = dM; sf = fbM; sn = fnM; }
+    if (hasD && dD > md) { md = dD; sf = fbD; sn = fnD; }
+    if (!(md > 0.0)) {
+        md = 0.0;
+        sf = fb_row0;
+        sn = fn_row0;
+    }
+    sc = fmax(fabs(sf), fabs(sn));
+}
+
 enum Phase {
-    PH_F0 = 0, PH_F1, PH_JAC, PH_NEWTON,
+    PH_F0 = 0, PH_F1, PH_JAC, PH_JAC_REDO, PH_NEWTON,
     C_JAC_FIN, C_STEP_BEGIN, C_STEP_TRY, C_NEWTON_BEGIN, C_NEWTON_FAIL, C_ERR_TEST, C_ACCEPT,
     C_SUCCESS, C_FAIL
 };
@@ -250,6 +273,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     double *V = wave_base + (size_t)wave * (NVEC * SLOTS + WAVE_SCRATCH);
     double *ru = V + NVEC * SLOTS;
     double *row0 = ru + 108;                    // f_new[group][row 0], <= 16 groups
+    int *flags_lds = reinterpret_cast<int *>(ru + 124);   // per-lane column flags of the FD-Jacobian retry pass
     double *Dv = V + V_D0 * SLOTS;
     const ColumnDev &P = A.P;
     const int D = P.D;
@@ -330,6 +354,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 double dy_norm_old = -1.0, safety = 0.0, error_norm = 0.0;
                 int order = 1, n_equal = 0, have_lu = 0, current_jac = 0, newton_k = 0, n_iter = 0;
                 int g = 0, jac_init = 1, nfev = 0, njev = 0, nlu = 0, nsteps = 0, ok = 0;
+                int redo_mask = 0, jac_stage = 0;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
                     ycur[c] = yrow0[c];
@@ -430,7 +455,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             need_rhs = false;
                         }
                     } else if (phase == C_JAC_FIN) {
-                        // _sparse_num_jac: per-column max |diff| (rows j-1, j, j+1), its scale, factor update
+                        // _sparse_num_jac: per-column max |diff| (rows j-1, j, j+1), its scale, factor update,
+                        // J = diff / h.  jac_stage 0 = first look, 1 = after the retry pass below.
                         __builtin_amdgcn_wave_barrier();
                         double fb[CPL];
 #pragma unroll
@@ -439,8 +465,9 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         const double fbD0 = shfl_down1(fb[0], lane, 0.0), fnD0 = shfl_down1(jl[0], lane, 0.0);
                         const double hU0 = shfl_up1(hj[CPL - 1], lane, 1.0), hD0 = shfl_down1(hj[0], lane, 1.0);
                         const double fb_row0 = readlane_d(fb[0], 0);
-                        bool small_any = false;
-                        double njl[CPL], njd[CPL], nju[CPL];
+                        const int old_flags = jac_stage ? flags_lds[lane] : 0;     // bit c: small, bit 16+c: factor done
+                        int small_bits = 0, my_groups = 0;
+                        double njl[CPL], njd[CPL], nju[CPL], nfac[CPL];
 #pragma unroll
                         for (int c = 0; c < CPL; c++) {
                             const int i = lane * CPL + c;
@@ -449,27 +476,19 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             const double fbD = c == CPL - 1 ? fbD0 : fb[c < CPL - 1 ? c + 1 : c];
                             const double fnD = c == CPL - 1 ? fnD0 : jl[c < CPL - 1 ? c + 1 : c];
                             const bool hasU = i >= 1, hasD = i < D - 1;
-                            const double dU = hasU ? fabs(fnU - fbU) : -1.0;
-                            const double dM = fabs(jd[c] - fb[c]);
-                            const double dD = hasD ? fabs(fnD - fbD) : -1.0;
-                            // first maximum in row order j-1, j, j+1
-                            double md = dU, sf = fbU, sn = fnU;
-                            if (!(dU >= dM)) { md = dM; sf = fb[c]; sn = jd[c]; }
-                            if (hasD && dD > md) { md = dD; sf = fbD; sn = fnD; }
-                            if (!(md > 0.0)) {   // all-zero column: scipy's sparse argmax lands on row 0
-                                md = 0.0;
-                                sf = fb_row0;
-                                sn = row0[gs[c] >= 0 ? gs[c] : 0];
-                            }
-                            const double sc = fmax(fabs(sf), fabs(sn));
-                            if (vnode[c]) {
-                                small_any = small_any || (md < NUM_JAC_DIFF_REJECT * sc);
-                                const int slot = c * WAVE + lane;
-                                double fac = V[V_FAC * SLOTS + slot];
+                            double md, sc;
+                            col_stats(hasU, hasD, fnU, fbU, jd[c], fb[c], fnD, fbD, row0[gs[c] >= 0 ? gs[c] : 0], fb_row0,
+                                      md, sc);
+                            const bool small = vnode[c] && (md < A.jac_reject * sc);
+                            small_bits |= small ? (1 << c) : 0;
+                            my_groups |= small ? (1 << gs[c]) : 0;
+                            double fac = V[V_FAC * SLOTS + c * WAVE + lane];
+                            if (!((old_flags >> (16 + c)) & 1)) {
                                 if (md < NUM_JAC_DIFF_SMALL * sc) fac *= 10.0;
                                 if (md > NUM_JAC_DIFF_BIG * sc) fac *= 0.1;
-                                V[V_FAC * SLOTS + slot] = fmax(fac, NUM_JAC_MIN_FACTOR);
+                                fac = fmax(fac, NUM_JAC_MIN_FACTOR);
                             }
+                            nfac[c] = fac;
                             // J row i: (f_new[i] - f[i]) / h[column]
                             const double hU = c == 0 ? hU0 : hj[c > 0 ? c - 1 : 0];
                             const double hD = c == CPL - 1 ? hD0 : hj[c < CPL - 1 ? c + 1 : c];
@@ -477,34 +496,117 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             njd[c] = vnode[c] ? (jd[c] - fb[c]) / hj[c] : 0.0;
                             nju[c] = hasD ? (ju[c] - fb[c]) / hD : 0.0;
                         }
-#pragma unroll
-                        for (int c = 0; c < CPL; c++) {
-                            jl[c] = njl[c];
-                            jd[c] = njd[c];
-                            ju[c] = nju[c];
-                        }
-                        if (__any(small_any)) {
-                            // num_jac's "difference too small -> retry with 10x step" branch is not implemented;
-                            // it is counted so that no run can take it silently (never seen on this model).
+                        if (jac_stage == 0 && __any(small_bits != 0)) {
+                            // rare: some column moved f by less than EPS^0.875 of its size -> retry those columns
+                            // with a 10x step, group by group (num_jac's diff_too_small branch); nothing committed yet
+                            redo_mask = 0;
+                            for (int q = 0; q < P.n_groups; q++)
+                                if (__any((my_groups >> q) & 1)) redo_mask |= 1 << q;
+                            redo_mask = uniform_i(redo_mask);
+                            flags_lds[lane] = small_bits;
+                            __builtin_amdgcn_wave_barrier();
                             if (lane == 0) atomicAdd(&A.counters[0], 1ull);
-                        }
-                        if (jac_init) {
-                            // rest of BDF.__init__: D[0] = y, D[1] = f0 * h_abs, order = 1
+                            jac_stage = 1;
+                            g = __ffs(redo_mask) - 1;
 #pragma unroll
                             for (int c = 0; c < CPL; c++) {
-                                const int slot = c * WAVE + lane;
-                                Dv[1 * SLOTS + slot] = Dv[1 * SLOTS + slot] * h_abs;
+                                const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
+                                const double hn = (yp[c] + 10.0 * V[V_FAC * SLOTS + c * WAVE + lane] * ysc) - yp[c];
+                                ycur[c] = yp[c] + ((((small_bits >> c) & 1) && gs[c] == g) ? hn : 0.0);
                             }
-                            order = 1;
-                            n_equal = 0;
-                            have_lu = 0;
-                            phase = C_STEP_BEGIN;
+                            phase = PH_JAC_REDO;
                         } else {
-                            have_lu = 0;
-                            current_jac = 1;
-                            phase = C_NEWTON_BEGIN;
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                jl[c] = njl[c];
+                                jd[c] = njd[c];
+                                ju[c] = nju[c];
+                                if (vnode[c]) V[V_FAC * SLOTS + c * WAVE + lane] = nfac[c];
+                            }
+                            jac_stage = 0;
+                            if (jac_init) {
+                                // rest of BDF.__init__: D[0] = y, D[1] = f0 * h_abs, order = 1
+#pragma unroll
+                                for (int c = 0; c < CPL; c++) {
+                                    const int slot = c * WAVE + lane;
+                                    Dv[1 * SLOTS + slot] = Dv[1 * SLOTS + slot] * h_abs;
+                                }
+                                order = 1;
+                                n_equal = 0;
+                                have_lu = 0;
+                                phase = C_STEP_BEGIN;
+                            } else {
+                                have_lu = 0;
+                                current_jac = 1;
+                                phase = C_NEWTON_BEGIN;
+                            }
+                            need_rhs = false;
                         }
-                        need_rhs = false;
+                    } else if (phase == PH_JAC_REDO) {
+                        // f = fun(y + h_new * [column small and in group g]); keep the new column where
+                        // max_diff * scale_new < max_diff_new * scale  (common.py _sparse_num_jac)
+                        __builtin_amdgcn_wave_barrier();
+                        double fb[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) fb[c] = V[V_FP * SLOTS + c * WAVE + lane];
+                        const double fbU0 = shfl_up1(fb[CPL - 1], lane, 0.0), fbD0 = shfl_down1(fb[0], lane, 0.0);
+                        const double fU0 = shfl_up1(f[CPL - 1], lane, 0.0), fD0 = shfl_down1(f[0], lane, 0.0);
+                        const double fnU0 = shfl_up1(ju[CPL - 1], lane, 0.0), fnD0 = shfl_down1(jl[0], lane, 0.0);
+                        const double fb_row0 = readlane_d(fb[0], 0), f_row0 = readlane_d(f[0], 0);
+                        int flags = flags_lds[lane];
+                        double upd[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            const int i = lane * CPL + c, slot = c * WAVE + lane;
+                            const bool hasU = i >= 1, hasD = i < D - 1;
+                            const double fbU = c == 0 ? fbU0 : fb[c > 0 ? c - 1 : 0];
+                            const double fbD = c == CPL - 1 ? fbD0 : fb[c < CPL - 1 ? c + 1 : c];
+                            const double fnU = c == 0 ? fnU0 : ju[c > 0 ? c - 1 : 0];
+                            const double fnD = c == CPL - 1 ? fnD0 : jl[c < CPL - 1 ? c + 1 : c];
+                            const double f2U = c == 0 ? fU0 : f[c > 0 ? c - 1 : 0];
+                            const double f2D = c == CPL - 1 ? fD0 : f[c < CPL - 1 ? c + 1 : c];
+                            double md, sc, md2, sc2;
+                            col_stats(hasU, hasD, fnU, fbU, jd[c], fb[c], fnD, fbD, row0[gs[c] >= 0 ? gs[c] : 0], fb_row0,
+                                      md, sc);
+                            col_stats(hasU, hasD, f2U, fbU, f[c], fb[c], f2D, fbD, f_row0, fb_row0, md2, sc2);
+                            const bool mine = ((flags >> c) & 1) && gs[c] == g;
+                            const bool u = mine && (md * sc2 < md2 * sc);
+                            upd[c] = u ? 1.0 : 0.0;
+                            if (u) {
+                                double fac = 10.0 * V[V_FAC * SLOTS + slot];
+                                const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
+                                hj[c] = (yp[c] + fac * ysc) - yp[c];
+                                if (md2 < NUM_JAC_DIFF_SMALL * sc2) fac *= 10.0;
+                                if (md2 > NUM_JAC_DIFF_BIG * sc2) fac *= 0.1;
+                                V[V_FAC * SLOTS + slot] = fmax(fac, NUM_JAC_MIN_FACTOR);
+                                flags |= 1 << (16 + c);
+                            }
+                        }
+                        flags_lds[lane] = flags;
+                        const double updU0 = shfl_up1(upd[CPL - 1], lane, 0.0), updD0 = shfl_down1(upd[0], lane, 0.0);
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            const double uU = c == 0 ? updU0 : upd[c > 0 ? c - 1 : 0];
+                            const double uD = c == CPL - 1 ? updD0 : upd[c < CPL - 1 ? c + 1 : c];
+                            jl[c] = uU != 0.0 ? f[c] : jl[c];
+                            jd[c] = upd[c] != 0.0 ? f[c] : jd[c];
+                            ju[c] = uD != 0.0 ? f[c] : ju[c];
+                        }
+                        redo_mask &= ~(1 << g);
+                        if (redo_mask != 0) {
+                            g = __ffs(redo_mask) - 1;
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
+                                const bool done = (flags >> (16 + c)) & 1;   // an updated column already holds 10x its factor
+                                const double fac0 = V[V_FAC * SLOTS + c * WAVE + lane];
+                                const double hn = (yp[c] + 10.0 * fac0 * ysc) - yp[c];
+                                ycur[c] = yp[c] + ((((flags >> c) & 1) && !done && gs[c] == g) ? hn : 0.0);
+                            }
+                        } else {
+                            phase = C_JAC_FIN;
+                            need_rhs = false;
+                        }
                     } else if (phase == C_STEP_BEGIN) {
                         // _step_impl entry
                         min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);

@@ -136,6 +136,12 @@ class EnsembleStepper:
         out["kernel_ms"], out["launches"] = a.kernel_ms, a.launches
         return out
 
+    def counters(self):
+        """{'jac_retry': ..., 'failed_attempts': ..., 'guard_trips': ...} since the handle was created."""
+        out = (C.c_uint64 * 4)()
+        L.check(self.lib.hc_get_counters(self.h, out))
+        return {"jac_retry": int(out[0]), "failed_attempts": int(out[1]), "guard_trips": int(out[2])}
+
     def moments(self):
         m = np.zeros((3, self.T), dtype=np.int64)
         L.check(self.lib.hc_get_moments(self.h, L.lptr(m)))

@@ -114,6 +114,10 @@ typedef struct {
 
 int hc_step_rows(hc_handle *h, hc_step_args *a);
 int hc_synchronize(hc_handle *h);
+/* event counters since hc_create: [0] FD-Jacobian passes that took num_jac's "difference too small ->
+ * retry with a 10x step" branch, [1] failed BDF attempts (each scales the noise by 0.8), [2] kernel
+ * iteration-guard trips (always 0; hc_step_rows fails otherwise), [3] reserved */
+int hc_get_counters(hc_handle *h, uint64_t *out4);
 
 /* moments: [3][n_forcing_rows] int64 = count, sum(idx), sum(idx^2) of wtd_est over members */
 int hc_get_moments(hc_handle *h, int64_t *moments);

@@ -372,6 +372,12 @@ typedef struct {
     int ipiv[HO_MAXD];
 } bdf_t;
 
+/* test hooks: override EPS**0.875 to exercise num_jac's retry branch; count how often it is taken */
+static double g_jac_reject = NUM_JAC_DIFF_REJECT;
+static long g_jac_retry_count = 0;
+void ho_debug_set_jac_reject(double v) { g_jac_reject = v > 0.0 ? v : NUM_JAC_DIFF_REJECT; }
+long ho_debug_jac_retry_count(void) { return g_jac_retry_count; }
+
 static void fun(bdf_t *b, const double *y, double *f)
 {
     ho_rhs(b->c, b->r, y, b->n_rnd, f, NULL);
@@ -431,10 +437,11 @@ static void num_jac(bdf_t *b, const double *y, const double *f, double threshold
         int mi = col_argmax(absd, r0, r1);
         max_diff[j] = (mi >= r0 && mi <= r1) ? absd[mi - r0] : 0.0;
         scale[j] = np_maximum(fabs(f[mi]), fabs(f_new[groups[j]][mi]));
-        too_small[j] = max_diff[j] < NUM_JAC_DIFF_REJECT * scale[j];
+        too_small[j] = max_diff[j] < g_jac_reject * scale[j];
         any_small |= too_small[j];
     }
     if (any_small) {
+        g_jac_retry_count++;
         double new_factor[HO_MAXD], h_new[HO_MAXD];
         int used[16] = {0};
         for (int j = 0; j < n; j++) {

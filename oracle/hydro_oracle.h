@@ -84,6 +84,10 @@ void ho_run(const ho_column *c, int64_t T, const double *precip, const double *a
 int ho_spinup(const ho_column *c, const ho_row *row0, double zwtd0_cm, const double *z,
               double *psi, double *n_rnd, int max_iter);
 
+/* test hooks (num_jac retry branch) */
+void ho_debug_set_jac_reject(double v);
+long ho_debug_jac_retry_count(void);
+
 #ifdef __cplusplus
 }
 #endif

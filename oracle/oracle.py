@@ -75,6 +75,10 @@ def lib():
         L.ho_run.restype = None
         L.ho_spinup.argtypes = [C.POINTER(HoColumn), C.POINTER(HoRow), C.c_double, _dp, _dp, _dp, C.c_int]
         L.ho_spinup.restype = C.c_int
+        L.ho_debug_set_jac_reject.argtypes = [C.c_double]
+        L.ho_debug_set_jac_reject.restype = None
+        L.ho_debug_jac_retry_count.argtypes = []
+        L.ho_debug_jac_retry_count.restype = C.c_long
         _lib = L
     return _lib
 

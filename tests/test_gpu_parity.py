@@ -470,3 +470,50 @@ def test_deep_reference_wells_match_oracle(gpu, dim_d):
         assert np.max(np.abs(y1[k] - r["psi"]) / (1 + np.abs(r["psi"]))) < 1e-3
         assert (out["stats"][:, k, 0] == r["per_row"][1:1 + rows, 0]).mean() >= 0.7
     st.close()
+
+
+def test_num_jac_retry_branch_matches_oracle(gpu, monkeypatch):
+    """scipy's num_jac retries a column with a 10x step when f moved by < EPS**0.875 of its size.
+
+    The model never gets there with the real threshold, so both sides raise it through their debug hooks
+    (HYDROCOL_DEBUG_JAC_REJECT / ho_debug_set_jac_reject) and must still agree row for row.
+    """
+    from oracle.oracle import lib as oracle_lib
+    _, cols, forcing = digest(200)
+    Y, n_rnd = _states(200)
+    keep = [0, 3]                                    # night_dry, dry_profile_day: regular rows
+    Y = Y[keep]
+    for reject in (1e-2, 0.3):
+        monkeypatch.setenv("HYDROCOL_DEBUG_JAC_REJECT", repr(reject))
+        oracle_lib().ho_debug_set_jac_reject(reject)
+        try:
+            st = gpu.EnsembleStepper(cols, forcing, len(Y))
+            o = _oracle(cols, forcing)
+            before = oracle_lib().ho_debug_jac_retry_count()
+            for row in (2, 24):
+                st.set_state(Y)
+                st.set_noise_host(np.tile(n_rnd, (len(Y), 1)))
+                out = st.step_rows(row, 1, fresh_noise=np.zeros((0,)), want_stats=True)
+                y1 = st.get_state()
+                for k in range(len(Y)):
+                    yo, so, _, _ = o.solve_row(_row(forcing, row), row - 1, row, Y[k], n_rnd)
+                    assert np.max(np.abs(y1[k] - yo) / (1 + np.abs(yo))) < 1e-6, (reject, row, k)
+                    assert out["stats"][0, k, :4].tolist() == [so["nfev"], so["njev"], so["nlu"], so["nsteps"]]
+            assert st.counters()["jac_retry"] > 0
+            assert oracle_lib().ho_debug_jac_retry_count() > before
+            st.close()
+        finally:
+            oracle_lib().ho_debug_set_jac_reject(0.0)
+            monkeypatch.delenv("HYDROCOL_DEBUG_JAC_REJECT")
+
+
+def test_default_runs_never_take_the_retry_branch(gpu):
+    _, cols, forcing = digest(200)
+    g = golden("g5_traj_200.npz")
+    st = gpu.EnsembleStepper(cols, forcing, 64)
+    st.set_state(g["initial_cond"])
+    st.set_noise_philox(8, 0)
+    st.step_rows(1, 96)
+    c = st.counters()
+    assert c["jac_retry"] == 0 and c["guard_trips"] == 0
+    st.close()
