@@ -34,10 +34,11 @@ enum { V_Y = 0, V_FP, V_NZ, V_FAC, V_D0, NVEC = V_D0 + MAX_ORDER + 3 };
 constexpr int WAVE_SCRATCH = 160;
 constexpr int MAX_PHASE_ITERATIONS = 60000;    // > 10x the costliest attempt observed (1419 RHS evaluations in a row)
 
-struct StepArgs {
-    ColumnDev P;
-    const double *tab;        // [NTAB][SLOTS]
-    const int *gtab;          // [NGTAB][SLOTS]
+// Kernel arguments.  Only what the hot loop needs stays in the kernarg segment; the column parameters
+// and the row-loop I/O pointers live in device memory and are (re)loaded through constant-address-space
+// scalar loads exactly where they are used (load_const below).  Keeping all of them in SGPRs for the
+// whole kernel made hipcc spill ~300 SGPRs to VGPR lanes, i.e. a v_readlane per use.
+struct IoArgs {
     double *psi;              // [N][D] in/out
     double *base_noise;       // [N][D] or null (Philox)
     const double *fresh;      // [n_fresh][N][D] or null
@@ -45,16 +46,37 @@ struct StepArgs {
     const double *precip, *atm;
     const unsigned char *daylight, *refresh;
     const int *wtd_obs, *draw_idx;
-    long long n_members, member_offset;
+    long long member_offset;
     long long row_begin;
-    int n_rows, spinup;
     unsigned long long seed;
     unsigned short *wtd_u16;  // [n_rows][N]
     int *stats;               // [n_rows][N][6] or null
     double *psi_rows;         // [n_rows][N][D] or null
-    unsigned long long *counters;   // [0] FD-Jacobian passes that retried columns with a 10x step, [1] failed attempts, [2] loop-guard trips
+    unsigned long long *counters;   // [0] FD-Jacobian retry passes, [1] failed attempts, [2] loop-guard trips
+};
+
+struct StepArgs {
+    const ColumnDev *P;       // device memory
+    const IoArgs *io;         // device memory
+    const double *tab;        // [NTAB][SLOTS]
+    const int *gtab;          // [NGTAB][SLOTS]
+    long long n_members;
+    int n_rows, spinup, D, n_groups, host_noise;
+    double psi_sat;
     double jac_reject;        // NUM_JAC_DIFF_REJECT = EPS**0.875 (debug override: HYDROCOL_DEBUG_JAC_REJECT)
 };
+
+// Uniform struct load from device memory through the constant address space (s_load_dwordxN).  The empty
+// asm makes the pointer opaque at this program point, so the loads cannot be hoisted out of the enclosing
+// loop and pinned in SGPRs for the kernel's lifetime.
+template <class T>
+__device__ __forceinline__ T load_const(const T *p)
+{
+    asm volatile("" : "+s"(p));
+    T out;
+    __builtin_memcpy(&out, (const __attribute__((address_space(4))) T *)p, sizeof(T));
+    return out;
+}
 
 // gamma = [0, cumsum(1/k)], alpha = (1 - kappa) * gamma, error_const = kappa * gamma + 1/(k+1)
 // with kappa = [0, -0.1850, -1/9, -0.0823, -0.0415, 0]  (bdf.py BDF.__init__), as NumPy evaluates them
@@ -275,8 +297,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     double *row0 = ru + 108;                    // f_new[group][row 0], <= 16 groups
     int *flags_lds = reinterpret_cast<int *>(ru + 124);   // per-lane column flags of the FD-Jacobian retry pass
     double *Dv = V + V_D0 * SLOTS;
-    const ColumnDev &P = A.P;
-    const int D = P.D;
+    const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
 
     bool vnode[CPL];
@@ -289,43 +310,54 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         gn[c] = gtab[G_NEXT * SLOTS + c * WAVE + lane];
     }
     // state -> LDS
+    double nscale = 1.0;
+    {
+        const IoArgs io = load_const(A.io);
 #pragma unroll
-    for (int c = 0; c < CPL; c++)
-        V[V_Y * SLOTS + c * WAVE + lane] = vnode[c] ? A.psi[member * D + lane * CPL + c] : 0.0;
-
-    double nscale = A.base_noise ? 1.0 : A.nscale[member];
+        for (int c = 0; c < CPL; c++)
+            V[V_Y * SLOTS + c * WAVE + lane] = vnode[c] ? io.psi[member * D + lane * CPL + c] : 0.0;
+        if (!A.host_noise) nscale = io.nscale[member];
+    }
     int fresh_seen = 0;
 
     for (int r = 0; r < A.n_rows; r++) {
-        const long long row = A.spinup ? A.row_begin : A.row_begin + r;
         RowDev R;
-        R.precip = A.precip[row];
-        R.atm = A.atm[row];
-        R.daylight = A.daylight[row];
-        R.wtd_obs = A.wtd_obs[row];
-        R.spinup = A.spinup;
-        const bool refresh = !A.spinup && A.refresh[row];
+        long long row;
+        bool refresh;
+        {
+            const IoArgs io = load_const(A.io);
+            row = A.spinup ? io.row_begin : io.row_begin + r;
+            R.precip = io.precip[row];
+            R.atm = io.atm[row];
+            R.daylight = io.daylight[row];
+            R.wtd_obs = io.wtd_obs[row];
+            R.spinup = A.spinup;
+            refresh = !A.spinup && io.refresh[row];
+        }
         const double t0 = A.spinup ? 0.0 : (double)(row - 1);
         const double tf = t0 + 1.0;
         int st_nfev = 0, st_njev = 0, st_nlu = 0, st_nsteps = 0, attempts = 0;
         bool skip = (R.wtd_obs < 0) && !A.spinup;    // simulation.py:582-588
         if (!skip) {
             // ---- noise vector of this row -> V_NZ (simulation.py:592,599-602)
+            {
+                const IoArgs io = load_const(A.io);
+                const unsigned draw = (refresh && !A.host_noise) ? (unsigned)io.draw_idx[row] : 0u;
 #pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                const int i = lane * CPL + c;
-                double z = 0.0;
-                if (vnode[c]) {
-                    if (A.base_noise) {
-                        z = refresh ? A.fresh[((size_t)fresh_seen * A.n_members + member) * D + i]
-                                    : A.base_noise[member * D + i];
-                    } else {
-                        const unsigned draw = refresh ? (unsigned)A.draw_idx[row] : 0u;
-                        z = philox_normal(A.seed, (unsigned long long)(A.member_offset + member), draw, (unsigned)i);
-                        z = refresh ? z : z * nscale;
+                for (int c = 0; c < CPL; c++) {
+                    const int i = lane * CPL + c;
+                    double z = 0.0;
+                    if (vnode[c]) {
+                        if (A.host_noise) {
+                            z = refresh ? io.fresh[((size_t)fresh_seen * A.n_members + member) * D + i]
+                                        : io.base_noise[member * D + i];
+                        } else {
+                            z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), draw, (unsigned)i);
+                            z = refresh ? z : z * nscale;
+                        }
                     }
+                    V[V_NZ * SLOTS + c * WAVE + lane] = z;
                 }
-                V[V_NZ * SLOTS + c * WAVE + lane] = z;
             }
             __builtin_amdgcn_wave_barrier();
             int failed = 0;
@@ -369,10 +401,13 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 int guard = 0;                       // every wave must reach an exit: bound the phase loop
                 for (;;) {
                     if (++guard > MAX_PHASE_ITERATIONS) {
-                        if (lane == 0) atomicAdd(&A.counters[2], 1ull);
+                        if (lane == 0) atomicAdd(&load_const(A.io).counters[2], 1ull);
                         phase = C_FAIL;
                     }
-                    if (need_rhs && phase < C_SUCCESS) rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr);
+                    if (need_rhs && phase < C_SUCCESS) {
+                        const ColumnDev P = load_const(A.P);
+                        rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr);
+                    }
                     need_rhs = true;
                     if (phase == PH_F0) {
                         // BDF.__init__: f0 = fun(t0, y0); select_initial_step part 1
@@ -447,7 +482,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             }
                             g++;
                         }
-                        if (g < P.n_groups) {
+                        if (g < A.n_groups) {
 #pragma unroll
                             for (int c = 0; c < CPL; c++) ycur[c] = yp[c] + ((gs[c] == g) ? hj[c] : 0.0);
                         } else {
@@ -500,12 +535,12 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             // rare: some column moved f by less than EPS^0.875 of its size -> retry those columns
                             // with a 10x step, group by group (num_jac's diff_too_small branch); nothing committed yet
                             redo_mask = 0;
-                            for (int q = 0; q < P.n_groups; q++)
+                            for (int q = 0; q < A.n_groups; q++)
                                 if (__any((my_groups >> q) & 1)) redo_mask |= 1 << q;
                             redo_mask = uniform_i(redo_mask);
                             flags_lds[lane] = small_bits;
                             __builtin_amdgcn_wave_barrier();
-                            if (lane == 0) atomicAdd(&A.counters[0], 1ull);
+                            if (lane == 0) atomicAdd(&load_const(A.io).counters[0], 1ull);
                             jac_stage = 1;
                             g = __ffs(redo_mask) - 1;
 #pragma unroll
@@ -816,11 +851,12 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 if (attempts >= 5) break;
             }
             if (failed) {
-                if (lane == 0) atomicAdd(&A.counters[1], (unsigned long long)failed);
-                if (!refresh && A.base_noise) {
+                const IoArgs io = load_const(A.io);
+                if (lane == 0) atomicAdd(&io.counters[1], (unsigned long long)failed);
+                if (!refresh && A.host_noise) {
 #pragma unroll
                     for (int c = 0; c < CPL; c++)
-                        if (vnode[c]) A.base_noise[member * D + lane * CPL + c] = V[V_NZ * SLOTS + c * WAVE + lane];
+                        if (vnode[c]) io.base_noise[member * D + lane * CPL + c] = V[V_NZ * SLOTS + c * WAVE + lane];
                 }
             }
             if (refresh) fresh_seen++;
@@ -831,29 +867,36 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
             yv[c] = V[V_Y * SLOTS + c * WAVE + lane];
-            unsat[c] = vnode[c] && !(yv[c] >= P.psi_sat);
+            unsat[c] = vnode[c] && !(yv[c] >= A.psi_sat);
         }
         const int istar = deepest_true<CPL>(unsat);
         int w = istar < 0 ? 0 : istar + 1;
         w = w < D - 1 ? w : D - 1;
         if (skip) w = 0;
-        if (lane == 0) {
-            A.wtd_u16[(size_t)r * A.n_members + member] = (unsigned short)w;
-            if (A.stats) {
-                int *s = A.stats + ((size_t)r * A.n_members + member) * 6;
-                s[0] = st_nfev; s[1] = st_njev; s[2] = st_nlu; s[3] = st_nsteps; s[4] = attempts; s[5] = refresh;
+        {
+            const IoArgs io = load_const(A.io);
+            if (lane == 0) {
+                io.wtd_u16[(size_t)r * A.n_members + member] = (unsigned short)w;
+                if (io.stats) {
+                    int *s = io.stats + ((size_t)r * A.n_members + member) * 6;
+                    s[0] = st_nfev; s[1] = st_njev; s[2] = st_nlu; s[3] = st_nsteps; s[4] = attempts; s[5] = refresh;
+                }
+            }
+            if (io.psi_rows) {
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                    if (vnode[c])
+                        io.psi_rows[((size_t)r * A.n_members + member) * D + lane * CPL + c] = skip ? 0.0 : yv[c];
             }
         }
-        if (A.psi_rows) {
-#pragma unroll
-            for (int c = 0; c < CPL; c++)
-                if (vnode[c]) A.psi_rows[((size_t)r * A.n_members + member) * D + lane * CPL + c] = skip ? 0.0 : yv[c];
-        }
     }
+    {
+        const IoArgs io = load_const(A.io);
 #pragma unroll
-    for (int c = 0; c < CPL; c++)
-        if (vnode[c]) A.psi[member * D + lane * CPL + c] = V[V_Y * SLOTS + c * WAVE + lane];
-    if (!A.base_noise && lane == 0) A.nscale[member] = nscale;
+        for (int c = 0; c < CPL; c++)
+            if (vnode[c]) io.psi[member * D + lane * CPL + c] = V[V_Y * SLOTS + c * WAVE + lane];
+        if (!A.host_noise && lane == 0) io.nscale[member] = nscale;
+    }
 }
 
 }  // namespace hc

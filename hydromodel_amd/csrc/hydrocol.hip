@@ -79,6 +79,9 @@ struct hc_handle {
     DevBuf<unsigned short> wtd_u16;
     DevBuf<long long> moments;
     DevBuf<unsigned long long> counters;
+    DevBuf<ColumnDev> Pdev;
+    DevBuf<IoArgs> iodev;
+    IoArgs io_host{};
     std::vector<unsigned char> h_refresh;
     int64_t n_rows = 0, n_members = 0;
     bool philox = false;
@@ -160,26 +163,27 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
     const long long member = (long long)blockIdx.x * WPB + wave;
     if (member >= A.n_members) return;
     double *nz = nzbase + wave * SLOTS;
-    const ColumnDev &P = A.P;
+    const ColumnDev P = load_const(A.P);
+    const IoArgs io = load_const(A.io);
     const int D = P.D;
     RowDev R;
-    R.precip = A.precip[row];
-    R.atm = A.atm[row];
-    R.daylight = A.daylight[row];
-    R.wtd_obs = A.wtd_obs[row];
+    R.precip = io.precip[row];
+    R.atm = io.atm[row];
+    R.daylight = io.daylight[row];
+    R.wtd_obs = io.wtd_obs[row];
     R.spinup = A.spinup;
     double y[CPL], rnd[CPL], f[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const int i = lane * CPL + c;
-        y[c] = i < D ? A.psi[member * D + i] : 0.0;
+        y[c] = i < D ? io.psi[member * D + i] : 0.0;
         double z = 0.0;
         if (i < D) {
-            if (A.base_noise)
-                z = A.base_noise[member * D + i];
+            if (A.host_noise)
+                z = io.base_noise[member * D + i];
             else
-                z = philox_normal(A.seed, (unsigned long long)(A.member_offset + member), 0u, (unsigned)i) *
-                    A.nscale[member];
+                z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), 0u, (unsigned)i) *
+                    io.nscale[member];
         }
         nz[c * WAVE + lane] = z;
     }
@@ -203,7 +207,8 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
 __global__ void model_nodes_kernel(const StepArgs A, const double *node_tabs, int special, double *out,
                                    double *qinf)
 {
-    const ColumnDev &P = A.P;
+    const ColumnDev P = load_const(A.P);
+    const IoArgs io = load_const(A.io);
     const int D = P.D;
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)A.n_members * D;
@@ -213,15 +218,15 @@ __global__ void model_nodes_kernel(const StepArgs A, const double *node_tabs, in
     const double por = node_tabs[i], meank = node_tabs[D + i], noisec = node_tabs[2 * D + i];
     const double mk = meank == 0.0 ? 1.0e-7 : meank;
     double z;
-    if (A.base_noise)
-        z = A.base_noise[member * D + i];
+    if (A.host_noise)
+        z = io.base_noise[member * D + i];
     else
-        z = philox_normal(A.seed, (unsigned long long)(A.member_offset + member), 0u, (unsigned)i) * A.nscale[member];
+        z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), 0u, (unsigned)i) * io.nscale[member];
     double th, K, C, kb, pf;
     if (special)
-        model_cell<true>(P, A.psi[k], por, 1.0 / (por - P.theta_res), log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
+        model_cell<true>(P, io.psi[k], por, 1.0 / (por - P.theta_res), log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
     else
-        model_cell<false>(P, A.psi[k], por, 1.0 / (por - P.theta_res), log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
+        model_cell<false>(P, io.psi[k], por, 1.0 / (por - P.theta_res), log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
     out[k] = th;
     out[total + k] = K;
     out[2 * total + k] = C;
@@ -288,6 +293,11 @@ int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, d
     return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= %d", h->p.dim_d, h->cpl, \
                 HC_MAX_DEPTH_NODES)
 
+int push_io(hc_handle *h)
+{
+    HIP_TRY(hipMemcpyAsync(h->iodev.p, &h->io_host, sizeof(IoArgs), hipMemcpyHostToDevice, h->stream));
+    return HC_OK;
+}
 int launch_step(hc_handle *h, const StepArgs &A) { HC_DISPATCH(launch_step_t, h, A); }
 int launch_rhs(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
 {
@@ -301,23 +311,31 @@ int fill_args(hc_handle *h, StepArgs &A)
     if (h->n_members <= 0 || !h->psi.p) return fail(HC_ERR_ARG, "hc_set_members / hc_set_state has not been called");
     if (!h->have_noise) return fail(HC_ERR_ARG, "no noise source: call hc_set_noise_host or hc_set_noise_philox");
     memset(&A, 0, sizeof(A));
-    A.P = h->P;
+    IoArgs &io = h->io_host;
+    memset(&io, 0, sizeof(io));
+    if (h->Pdev.ensure(1) || h->iodev.ensure(1)) return HC_ERR_DEVICE;
+    A.P = h->Pdev.p;
+    A.io = h->iodev.p;
     A.tab = h->tab.p;
     A.gtab = h->gtab.p;
-    A.psi = h->psi.p;
-    A.base_noise = h->philox ? nullptr : h->base.p;
-    A.nscale = h->nscale.p;
-    A.precip = h->precip.p;
-    A.atm = h->atm.p;
-    A.daylight = h->daylight.p;
-    A.refresh = h->refresh.p;
-    A.wtd_obs = h->wtd_obs.p;
-    A.draw_idx = h->draw_idx.p;
     A.n_members = h->n_members;
-    A.member_offset = h->member_offset;
-    A.seed = h->seed;
-    A.counters = h->counters.p;
+    A.D = h->P.D;
+    A.n_groups = h->P.n_groups;
+    A.host_noise = h->philox ? 0 : 1;
+    A.psi_sat = h->P.psi_sat;
     A.jac_reject = h->jac_reject;
+    io.psi = h->psi.p;
+    io.base_noise = h->philox ? nullptr : h->base.p;
+    io.nscale = h->nscale.p;
+    io.precip = h->precip.p;
+    io.atm = h->atm.p;
+    io.daylight = h->daylight.p;
+    io.refresh = h->refresh.p;
+    io.wtd_obs = h->wtd_obs.p;
+    io.draw_idx = h->draw_idx.p;
+    io.member_offset = h->member_offset;
+    io.seed = h->seed;
+    io.counters = h->counters.p;
     return HC_OK;
 }
 
@@ -364,6 +382,7 @@ int hc_destroy(hc_handle *h)
     h->tab.release(); h->node_tabs.release(); h->precip.release(); h->atm.release(); h->psi.release();
     h->base.release(); h->nscale.release(); h->fresh.release(); h->psi_rows.release(); h->scratch_d.release();
     h->gtab.release(); h->wtd_obs.release(); h->draw_idx.release(); h->stats.release(); h->scratch_i.release();
+    h->Pdev.release(); h->iodev.release();
     h->daylight.release(); h->refresh.release(); h->wtd_u16.release(); h->moments.release(); h->counters.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -440,6 +459,8 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
     HIP_TRY(hipMemcpy(h->tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->gtab.p, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->node_tabs.p, node_tabs, (size_t)3 * D * 8, hipMemcpyHostToDevice));
+    if (h->Pdev.ensure(1)) return HC_ERR_DEVICE;
+    HIP_TRY(hipMemcpy(h->Pdev.p, &h->P, sizeof(ColumnDev), hipMemcpyHostToDevice));
     h->have_column = true;
     return HC_OK;
 }
@@ -610,13 +631,15 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
         if (h->wtd_u16.ensure((size_t)chunk * N)) return HC_ERR_DEVICE;
         if (a->stats_out && h->stats.ensure((size_t)chunk * N * 6)) return HC_ERR_DEVICE;
         if (a->psi_rows_out && h->psi_rows.ensure((size_t)chunk * N * D)) return HC_ERR_DEVICE;
-        A.fresh = h->fresh.p;
-        A.row_begin = row0;
+        h->io_host.fresh = h->fresh.p;
+        h->io_host.row_begin = row0;
         A.n_rows = chunk;
         A.spinup = a->spinup;
-        A.wtd_u16 = h->wtd_u16.p;
-        A.stats = a->stats_out ? h->stats.p : nullptr;
-        A.psi_rows = a->psi_rows_out ? h->psi_rows.p : nullptr;
+        h->io_host.wtd_u16 = h->wtd_u16.p;
+        h->io_host.stats = a->stats_out ? h->stats.p : nullptr;
+        h->io_host.psi_rows = a->psi_rows_out ? h->psi_rows.p : nullptr;
+        rc = push_io(h);
+        if (rc) return rc;
         HIP_TRY(hipEventRecord(h->ev0, h->stream));
         rc = launch_step(h, A);
         if (rc) return rc;
@@ -711,6 +734,8 @@ int hc_rhs(hc_handle *h, int64_t row, int32_t spinup, double *dydt, double *aux)
     const size_t n = (size_t)h->n_members * D, na = (size_t)h->n_members * (3 * (D - 1) + 1);
     if (h->scratch_d.ensure(n + (aux ? na : 0))) return HC_ERR_DEVICE;
     A.spinup = spinup;
+    rc = push_io(h);
+    if (rc) return rc;
     rc = launch_rhs(h, A, row, h->scratch_d.p, aux ? h->scratch_d.p + n : nullptr);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -729,6 +754,8 @@ int hc_model_nodes(hc_handle *h, double *out, double *qinf)
     const int D = h->p.dim_d;
     const size_t n = (size_t)h->n_members * D;
     if (h->scratch_d.ensure(4 * n + (size_t)h->n_members)) return HC_ERR_DEVICE;
+    rc = push_io(h);
+    if (rc) return rc;
     hipLaunchKernelGGL(model_nodes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, A,
                        h->node_tabs.p, (int)h->special, h->scratch_d.p, h->scratch_d.p + 4 * n);
     HIP_TRY(hipGetLastError());
