@@ -31,7 +31,11 @@ constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 
 // per-wave LDS vectors (each 64*CPL doubles)
 enum { V_Y = 0, V_FP, V_NZ, V_FAC, V_D0, NVEC = V_D0 + MAX_ORDER + 3 };
+#ifdef HC_PROFILE
+constexpr int WAVE_SCRATCH = 192;
+#else
 constexpr int WAVE_SCRATCH = 160;
+#endif
 constexpr int MAX_PHASE_ITERATIONS = 60000;    // > 10x the costliest attempt observed (1419 RHS evaluations in a row)
 
 // Kernel arguments.  Only what the hot loop needs stays in the kernarg segment; the column parameters
@@ -296,6 +300,11 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     double *ru = V + NVEC * SLOTS;
     double *row0 = ru + 108;                    // f_new[group][row 0], <= 16 groups
     int *flags_lds = reinterpret_cast<int *>(ru + 124);   // per-lane column flags of the FD-Jacobian retry pass
+#ifdef HC_PROFILE
+    unsigned long long *prof_lds = reinterpret_cast<unsigned long long *>(ru + 160);
+    if (lane < 32) prof_lds[lane] = 0;
+    int prof_slot = 31;
+#endif
     double *Dv = V + V_D0 * SLOTS;
     const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
@@ -397,19 +406,37 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     scl[c] = 1.0;
                 }
                 int phase = PH_F0;
-                bool need_rhs = true;
                 int guard = 0;                       // every wave must reach an exit: bound the phase loop
+#ifdef HC_PROFILE
+                unsigned long long prof_t = clock64();
+#endif
                 for (;;) {
+#ifdef HC_PROFILE
+                    {   // diagnostic build only: cycles per phase (the slot after the RHS site is phase + 16)
+                        const unsigned long long now = clock64();
+                        if (lane == 0) prof_lds[prof_slot] += (unsigned)(now - prof_t);
+                        prof_t = now;
+                        prof_slot = phase;
+                    }
+#endif
                     if (++guard > MAX_PHASE_ITERATIONS) {
                         if (lane == 0) atomicAdd(&load_const(A.io).counters[2], 1ull);
                         phase = C_FAIL;
                     }
-                    if (need_rhs && phase < C_SUCCESS) {
+                    if (phase < C_SUCCESS) {
                         const ColumnDev P = load_const(A.P);
                         rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr);
+#ifdef HC_PROFILE
+                        const unsigned long long now = clock64();
+                        if (lane == 0) prof_lds[16] += (unsigned)(now - prof_t);
+                        prof_t = now;
+#endif
                     }
-                    need_rhs = true;
-                    if (phase == PH_F0) {
+                    // Phases run in topological order inside ONE loop iteration: a block that hands over to a
+                    // later block falls through to it; only blocks that need a fresh RHS value end the iteration.
+                    bool have_f = true;
+                    if (phase == PH_F0 && have_f) {
+                        have_f = false;
                         // BDF.__init__: f0 = fun(t0, y0); select_initial_step part 1
                         nfev++;
                         double y0v[CPL];
@@ -432,7 +459,9 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             ycur[c] = y0v[c] + h0 * f[c];
                         }
                         phase = PH_F1;
-                    } else if (phase == PH_F1) {
+                    }
+                    if (phase == PH_F1 && have_f) {
+                        have_f = false;
                         // select_initial_step part 2 (order = 1)
                         nfev++;
                         double df[CPL];
@@ -451,8 +480,137 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         jac_init = 1;
                         g = -1;
                         phase = PH_JAC;
-                        need_rhs = false;
-                    } else if (phase == PH_JAC) {
+                    }
+                    if (phase == PH_NEWTON && have_f) {
+                        have_f = false;
+                        // solve_bdf_system, iteration newton_k
+                        nfev++;
+                        bool fin = true;
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) fin = fin && (!vnode[c] || isfinite(f[c]));
+                        if (newton_k == 0) {
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) V[V_FP * SLOTS + c * WAVE + lane] = f[c];
+                        }
+                        bool converged = false, failed_newton = false;
+                        if (!__all(fin)) {
+                            failed_newton = true;
+                        } else {
+                            double dy[CPL];
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) dy[c] = vnode[c] ? cc * f[c] - psiv[c] - dd[c] : 0.0;
+                            lu_solve<CPL>(F, dy, lane);
+                            const double dy_norm = rms_ratio<CPL>(dy, scl, lane, D, inv_sqrt_d);
+                            const bool have_rate = dy_norm_old >= 0.0;
+                            const double rate = have_rate ? dy_norm / dy_norm_old : 0.0;
+                            double rp = rate;
+                            for (int q = 1; q < NEWTON_MAXITER - newton_k; q++) rp *= rate;
+                            if (have_rate && (rate >= 1.0 || rp / (1.0 - rate) * dy_norm > NEWTON_TOL)) {
+                                failed_newton = true;
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < CPL; c++) {
+                                    ycur[c] += dy[c];
+                                    dd[c] += dy[c];
+                                }
+                                if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < NEWTON_TOL)) {
+                                    converged = true;
+                                } else {
+                                    dy_norm_old = dy_norm;
+                                    newton_k++;
+                                    if (newton_k == NEWTON_MAXITER) failed_newton = true;
+                                }
+                            }
+                        }
+                        if (converged) {
+                            n_iter = newton_k + 1;
+                            phase = C_ERR_TEST;
+                        } else if (failed_newton) {
+                            phase = C_NEWTON_FAIL;
+                        }
+                    }
+                    if (phase == C_NEWTON_FAIL) {
+                        if (current_jac) {
+                            h_abs *= 0.5;
+                            change_D<CPL>(Dv, ru, order, 0.5, lane);
+                            n_equal = 0;
+                            have_lu = 0;
+                            phase = C_STEP_TRY;
+                        } else {
+                            // J = jac(t_new, y_predict): base point yp, base f = fun(y_predict) kept in V_FP
+                            njev++;
+                            jac_init = 0;
+                            g = -1;
+                            phase = PH_JAC;
+                        }
+                    }
+                    if (phase == PH_JAC_REDO && have_f) {
+                        have_f = false;
+                        // f = fun(y + h_new * [column small and in group g]); keep the new column where
+                        // max_diff * scale_new < max_diff_new * scale  (common.py _sparse_num_jac)
+                        __builtin_amdgcn_wave_barrier();
+                        double fb[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) fb[c] = V[V_FP * SLOTS + c * WAVE + lane];
+                        const double fbU0 = shfl_up1(fb[CPL - 1], lane, 0.0), fbD0 = shfl_down1(fb[0], lane, 0.0);
+                        const double fU0 = shfl_up1(f[CPL - 1], lane, 0.0), fD0 = shfl_down1(f[0], lane, 0.0);
+                        const double fnU0 = shfl_up1(ju[CPL - 1], lane, 0.0), fnD0 = shfl_down1(jl[0], lane, 0.0);
+                        const double fb_row0 = readlane_d(fb[0], 0), f_row0 = readlane_d(f[0], 0);
+                        int flags = flags_lds[lane];
+                        double upd[CPL];
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            const int i = lane * CPL + c, slot = c * WAVE + lane;
+                            const bool hasU = i >= 1, hasD = i < D - 1;
+                            const double fbU = c == 0 ? fbU0 : fb[c > 0 ? c - 1 : 0];
+                            const double fbD = c == CPL - 1 ? fbD0 : fb[c < CPL - 1 ? c + 1 : c];
+                            const double fnU = c == 0 ? fnU0 : ju[c > 0 ? c - 1 : 0];
+                            const double fnD = c == CPL - 1 ? fnD0 : jl[c < CPL - 1 ? c + 1 : c];
+                            const double f2U = c == 0 ? fU0 : f[c > 0 ? c - 1 : 0];
+                            const double f2D = c == CPL - 1 ? fD0 : f[c < CPL - 1 ? c + 1 : c];
+                            double md, sc, md2, sc2;
+                            col_stats(hasU, hasD, fnU, fbU, jd[c], fb[c], fnD, fbD, row0[gs[c] >= 0 ? gs[c] : 0], fb_row0,
+                                      md, sc);
+                            col_stats(hasU, hasD, f2U, fbU, f[c], fb[c], f2D, fbD, f_row0, fb_row0, md2, sc2);
+                            const bool mine = ((flags >> c) & 1) && gs[c] == g;
+                            const bool u = mine && (md * sc2 < md2 * sc);
+                            upd[c] = u ? 1.0 : 0.0;
+                            if (u) {
+                                double fac = 10.0 * V[V_FAC * SLOTS + slot];
+                                const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
+                                hj[c] = (yp[c] + fac * ysc) - yp[c];
+                                if (md2 < NUM_JAC_DIFF_SMALL * sc2) fac *= 10.0;
+                                if (md2 > NUM_JAC_DIFF_BIG * sc2) fac *= 0.1;
+                                V[V_FAC * SLOTS + slot] = fmax(fac, NUM_JAC_MIN_FACTOR);
+                                flags |= 1 << (16 + c);
+                            }
+                        }
+                        flags_lds[lane] = flags;
+                        const double updU0 = shfl_up1(upd[CPL - 1], lane, 0.0), updD0 = shfl_down1(upd[0], lane, 0.0);
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            const double uU = c == 0 ? updU0 : upd[c > 0 ? c - 1 : 0];
+                            const double uD = c == CPL - 1 ? updD0 : upd[c < CPL - 1 ? c + 1 : c];
+                            jl[c] = uU != 0.0 ? f[c] : jl[c];
+                            jd[c] = upd[c] != 0.0 ? f[c] : jd[c];
+                            ju[c] = uD != 0.0 ? f[c] : ju[c];
+                        }
+                        redo_mask &= ~(1 << g);
+                        if (redo_mask != 0) {
+                            g = __ffs(redo_mask) - 1;
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
+                                const bool done = (flags >> (16 + c)) & 1;   // an updated column already holds 10x its factor
+                                const double fac0 = V[V_FAC * SLOTS + c * WAVE + lane];
+                                const double hn = (yp[c] + 10.0 * fac0 * ysc) - yp[c];
+                                ycur[c] = yp[c] + ((((flags >> c) & 1) && !done && gs[c] == g) ? hn : 0.0);
+                            }
+                        } else {
+                            phase = C_JAC_FIN;
+                        }
+                    }
+                    if (phase == PH_JAC) {
                         if (g < 0) {
                             // common.num_jac: step h per column from factor, f sign and |y|
 #pragma unroll
@@ -487,9 +645,9 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             for (int c = 0; c < CPL; c++) ycur[c] = yp[c] + ((gs[c] == g) ? hj[c] : 0.0);
                         } else {
                             phase = C_JAC_FIN;
-                            need_rhs = false;
                         }
-                    } else if (phase == C_JAC_FIN) {
+                    }
+                    if (phase == C_JAC_FIN) {
                         // _sparse_num_jac: per-column max |diff| (rows j-1, j, j+1), its scale, factor update,
                         // J = diff / h.  jac_stage 0 = first look, 1 = after the retry pass below.
                         __builtin_amdgcn_wave_barrier();
@@ -575,194 +733,9 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                                 current_jac = 1;
                                 phase = C_NEWTON_BEGIN;
                             }
-                            need_rhs = false;
                         }
-                    } else if (phase == PH_JAC_REDO) {
-                        // f = fun(y + h_new * [column small and in group g]); keep the new column where
-                        // max_diff * scale_new < max_diff_new * scale  (common.py _sparse_num_jac)
-                        __builtin_amdgcn_wave_barrier();
-                        double fb[CPL];
-#pragma unroll
-                        for (int c = 0; c < CPL; c++) fb[c] = V[V_FP * SLOTS + c * WAVE + lane];
-                        const double fbU0 = shfl_up1(fb[CPL - 1], lane, 0.0), fbD0 = shfl_down1(fb[0], lane, 0.0);
-                        const double fU0 = shfl_up1(f[CPL - 1], lane, 0.0), fD0 = shfl_down1(f[0], lane, 0.0);
-                        const double fnU0 = shfl_up1(ju[CPL - 1], lane, 0.0), fnD0 = shfl_down1(jl[0], lane, 0.0);
-                        const double fb_row0 = readlane_d(fb[0], 0), f_row0 = readlane_d(f[0], 0);
-                        int flags = flags_lds[lane];
-                        double upd[CPL];
-#pragma unroll
-                        for (int c = 0; c < CPL; c++) {
-                            const int i = lane * CPL + c, slot = c * WAVE + lane;
-                            const bool hasU = i >= 1, hasD = i < D - 1;
-                            const double fbU = c == 0 ? fbU0 : fb[c > 0 ? c - 1 : 0];
-                            const double fbD = c == CPL - 1 ? fbD0 : fb[c < CPL - 1 ? c + 1 : c];
-                            const double fnU = c == 0 ? fnU0 : ju[c > 0 ? c - 1 : 0];
-                            const double fnD = c == CPL - 1 ? fnD0 : jl[c < CPL - 1 ? c + 1 : c];
-                            const double f2U = c == 0 ? fU0 : f[c > 0 ? c - 1 : 0];
-                            const double f2D = c == CPL - 1 ? fD0 : f[c < CPL - 1 ? c + 1 : c];
-                            double md, sc, md2, sc2;
-                            col_stats(hasU, hasD, fnU, fbU, jd[c], fb[c], fnD, fbD, row0[gs[c] >= 0 ? gs[c] : 0], fb_row0,
-                                      md, sc);
-                            col_stats(hasU, hasD, f2U, fbU, f[c], fb[c], f2D, fbD, f_row0, fb_row0, md2, sc2);
-                            const bool mine = ((flags >> c) & 1) && gs[c] == g;
-                            const bool u = mine && (md * sc2 < md2 * sc);
-                            upd[c] = u ? 1.0 : 0.0;
-                            if (u) {
-                                double fac = 10.0 * V[V_FAC * SLOTS + slot];
-                                const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
-                                hj[c] = (yp[c] + fac * ysc) - yp[c];
-                                if (md2 < NUM_JAC_DIFF_SMALL * sc2) fac *= 10.0;
-                                if (md2 > NUM_JAC_DIFF_BIG * sc2) fac *= 0.1;
-                                V[V_FAC * SLOTS + slot] = fmax(fac, NUM_JAC_MIN_FACTOR);
-                                flags |= 1 << (16 + c);
-                            }
-                        }
-                        flags_lds[lane] = flags;
-                        const double updU0 = shfl_up1(upd[CPL - 1], lane, 0.0), updD0 = shfl_down1(upd[0], lane, 0.0);
-#pragma unroll
-                        for (int c = 0; c < CPL; c++) {
-                            const double uU = c == 0 ? updU0 : upd[c > 0 ? c - 1 : 0];
-                            const double uD = c == CPL - 1 ? updD0 : upd[c < CPL - 1 ? c + 1 : c];
-                            jl[c] = uU != 0.0 ? f[c] : jl[c];
-                            jd[c] = upd[c] != 0.0 ? f[c] : jd[c];
-                            ju[c] = uD != 0.0 ? f[c] : ju[c];
-                        }
-                        redo_mask &= ~(1 << g);
-                        if (redo_mask != 0) {
-                            g = __ffs(redo_mask) - 1;
-#pragma unroll
-                            for (int c = 0; c < CPL; c++) {
-                                const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
-                                const bool done = (flags >> (16 + c)) & 1;   // an updated column already holds 10x its factor
-                                const double fac0 = V[V_FAC * SLOTS + c * WAVE + lane];
-                                const double hn = (yp[c] + 10.0 * fac0 * ysc) - yp[c];
-                                ycur[c] = yp[c] + ((((flags >> c) & 1) && !done && gs[c] == g) ? hn : 0.0);
-                            }
-                        } else {
-                            phase = C_JAC_FIN;
-                            need_rhs = false;
-                        }
-                    } else if (phase == C_STEP_BEGIN) {
-                        // _step_impl entry
-                        min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
-                        if (h_abs < min_step) {
-                            change_D<CPL>(Dv, ru, order, min_step / h_abs, lane);
-                            h_abs = min_step;
-                            n_equal = 0;
-                        }
-                        current_jac = 0;
-                        phase = C_STEP_TRY;
-                        need_rhs = false;
-                    } else if (phase == C_STEP_TRY) {
-                        need_rhs = false;
-                        if (h_abs < min_step) {
-                            phase = C_FAIL;
-                        } else {
-                            t_new = t + h_abs;
-                            if (t_new - tf > 0.0) {
-                                t_new = tf;
-                                change_D<CPL>(Dv, ru, order, fabs(t_new - t) / h_abs, lane);
-                                n_equal = 0;
-                                have_lu = 0;
-                            }
-                            const double h = t_new - t;
-                            h_abs = fabs(h);
-                            const double inv_alpha = 1.0 / alpha_k(order);
-#pragma unroll
-                            for (int c = 0; c < CPL; c++) {
-                                const int slot = c * WAVE + lane;
-                                double s = Dv[slot], p = 0.0;
-                                for (int k = 1; k <= order; k++) {
-                                    const double dk = Dv[k * SLOTS + slot];
-                                    s += dk;
-                                    p += dk * gamma_k(k);
-                                }
-                                yp[c] = s;
-                                scl[c] = 1.0 / (ATOL + RTOL * fabs(s));
-                                psiv[c] = p * inv_alpha;
-                            }
-                            cc = h / alpha_k(order);
-                            phase = C_NEWTON_BEGIN;
-                        }
-                    } else if (phase == C_NEWTON_BEGIN) {
-                        if (!have_lu) {
-                            lu_factor<CPL>(F, jl, jd, ju, cc, lane, D);
-                            have_lu = 1;
-                            nlu++;
-                        }
-#pragma unroll
-                        for (int c = 0; c < CPL; c++) {
-                            dd[c] = 0.0;
-                            ycur[c] = yp[c];
-                        }
-                        newton_k = 0;
-                        dy_norm_old = -1.0;
-                        phase = PH_NEWTON;
-                    } else if (phase == PH_NEWTON) {
-                        // solve_bdf_system, iteration newton_k
-                        nfev++;
-                        bool fin = true;
-#pragma unroll
-                        for (int c = 0; c < CPL; c++) fin = fin && (!vnode[c] || isfinite(f[c]));
-                        if (newton_k == 0) {
-#pragma unroll
-                            for (int c = 0; c < CPL; c++) V[V_FP * SLOTS + c * WAVE + lane] = f[c];
-                        }
-                        bool converged = false, failed_newton = false;
-                        if (!__all(fin)) {
-                            failed_newton = true;
-                        } else {
-                            double dy[CPL];
-#pragma unroll
-                            for (int c = 0; c < CPL; c++) dy[c] = vnode[c] ? cc * f[c] - psiv[c] - dd[c] : 0.0;
-                            lu_solve<CPL>(F, dy, lane);
-                            const double dy_norm = rms_ratio<CPL>(dy, scl, lane, D, inv_sqrt_d);
-                            const bool have_rate = dy_norm_old >= 0.0;
-                            const double rate = have_rate ? dy_norm / dy_norm_old : 0.0;
-                            double rp = rate;
-                            for (int q = 1; q < NEWTON_MAXITER - newton_k; q++) rp *= rate;
-                            if (have_rate && (rate >= 1.0 || rp / (1.0 - rate) * dy_norm > NEWTON_TOL)) {
-                                failed_newton = true;
-                            } else {
-#pragma unroll
-                                for (int c = 0; c < CPL; c++) {
-                                    ycur[c] += dy[c];
-                                    dd[c] += dy[c];
-                                }
-                                if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < NEWTON_TOL)) {
-                                    converged = true;
-                                } else {
-                                    dy_norm_old = dy_norm;
-                                    newton_k++;
-                                    if (newton_k == NEWTON_MAXITER) failed_newton = true;
-                                }
-                            }
-                        }
-                        if (converged) {
-                            n_iter = newton_k + 1;
-                            phase = C_ERR_TEST;
-                            need_rhs = false;
-                        } else if (failed_newton) {
-                            phase = C_NEWTON_FAIL;
-                            need_rhs = false;
-                        }
-                    } else if (phase == C_NEWTON_FAIL) {
-                        need_rhs = false;
-                        if (current_jac) {
-                            h_abs *= 0.5;
-                            change_D<CPL>(Dv, ru, order, 0.5, lane);
-                            n_equal = 0;
-                            have_lu = 0;
-                            phase = C_STEP_TRY;
-                        } else {
-                            // J = jac(t_new, y_predict): base point yp, base f = fun(y_predict) kept in V_FP
-                            njev++;
-                            jac_init = 0;
-                            g = -1;
-                            phase = PH_JAC;
-                        }
-                    } else if (phase == C_ERR_TEST) {
-                        need_rhs = false;
+                    }
+                    if (phase == C_ERR_TEST) {
                         safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (double)(2 * NEWTON_MAXITER + n_iter);
                         const double ec = error_const_k(order);
                         double e[CPL];
@@ -781,8 +754,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         } else {
                             phase = C_ACCEPT;
                         }
-                    } else if (phase == C_ACCEPT) {
-                        need_rhs = false;
+                    }
+                    if (phase == C_ACCEPT) {
                         n_equal++;
                         t = t_new;
                         nsteps++;
@@ -832,7 +805,66 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             have_lu = 0;
                             phase = C_STEP_BEGIN;
                         }
-                    } else {
+
+                    }
+                    if (phase == C_STEP_BEGIN) {
+                        // _step_impl entry
+                        min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+                        if (h_abs < min_step) {
+                            change_D<CPL>(Dv, ru, order, min_step / h_abs, lane);
+                            h_abs = min_step;
+                            n_equal = 0;
+                        }
+                        current_jac = 0;
+                        phase = C_STEP_TRY;
+                    }
+                    if (phase == C_STEP_TRY) {
+                        if (h_abs < min_step) {
+                            phase = C_FAIL;
+                        } else {
+                            t_new = t + h_abs;
+                            if (t_new - tf > 0.0) {
+                                t_new = tf;
+                                change_D<CPL>(Dv, ru, order, fabs(t_new - t) / h_abs, lane);
+                                n_equal = 0;
+                                have_lu = 0;
+                            }
+                            const double h = t_new - t;
+                            h_abs = fabs(h);
+                            const double inv_alpha = 1.0 / alpha_k(order);
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                const int slot = c * WAVE + lane;
+                                double s = Dv[slot], p = 0.0;
+                                for (int k = 1; k <= order; k++) {
+                                    const double dk = Dv[k * SLOTS + slot];
+                                    s += dk;
+                                    p += dk * gamma_k(k);
+                                }
+                                yp[c] = s;
+                                scl[c] = 1.0 / (ATOL + RTOL * fabs(s));
+                                psiv[c] = p * inv_alpha;
+                            }
+                            cc = h / alpha_k(order);
+                            phase = C_NEWTON_BEGIN;
+                        }
+                    }
+                    if (phase == C_NEWTON_BEGIN) {
+                        if (!have_lu) {
+                            lu_factor<CPL>(F, jl, jd, ju, cc, lane, D);
+                            have_lu = 1;
+                            nlu++;
+                        }
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            dd[c] = 0.0;
+                            ycur[c] = yp[c];
+                        }
+                        newton_k = 0;
+                        dy_norm_old = -1.0;
+                        phase = PH_NEWTON;
+                    }
+                    if (phase >= C_SUCCESS) {
                         ok = (phase == C_SUCCESS);
                         break;
                     }
@@ -896,6 +928,10 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         for (int c = 0; c < CPL; c++)
             if (vnode[c]) io.psi[member * D + lane * CPL + c] = V[V_Y * SLOTS + c * WAVE + lane];
         if (!A.host_noise && lane == 0) io.nscale[member] = nscale;
+#ifdef HC_PROFILE
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) atomicAdd(&io.counters[8 + lane], prof_lds[lane]);
+#endif
     }
 }
 

@@ -277,6 +277,11 @@ int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, d
 }
 
 // waves per workgroup per CPL: as many as the 160 KB of LDS admit (tables + per-wave vectors)
+#ifdef HC_DEV_ONLY_CPL5
+#define HC_DISPATCH(FN, ...)                                                            \
+    if (h->cpl == 5 && h->special) return FN<5, true, 4>(__VA_ARGS__);                  \
+    return fail(HC_ERR_UNSUPPORTED, "development build: CPL 5 / special only")
+#else
 #define HC_DISPATCH(FN, ...)                                                            \
     switch (h->cpl) {                                                                   \
         case 2: return h->special ? FN<2, true, 4>(__VA_ARGS__) : FN<2, false, 4>(__VA_ARGS__); \
@@ -292,6 +297,7 @@ int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, d
     }                                                                                   \
     return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= %d", h->p.dim_d, h->cpl, \
                 HC_MAX_DEPTH_NODES)
+#endif
 
 int push_io(hc_handle *h)
 {
@@ -364,8 +370,8 @@ int hc_create(int device_ordinal, hc_handle **out)
     HIP_TRY(hipStreamCreate(&h->stream));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
-    if (h->counters.ensure(4) != HC_OK) return HC_ERR_DEVICE;
-    HIP_TRY(hipMemset(h->counters.p, 0, 4 * sizeof(unsigned long long)));
+    if (h->counters.ensure(64) != HC_OK) return HC_ERR_DEVICE;
+    HIP_TRY(hipMemset(h->counters.p, 0, 64 * sizeof(unsigned long long)));
     const char *rpl = getenv("HYDROCOL_ROWS_PER_LAUNCH");
     if (rpl && atoi(rpl) > 0) h->rows_per_launch = atoi(rpl);
     const char *jr = getenv("HYDROCOL_DEBUG_JAC_REJECT");   // test hook: exercises num_jac's retry branch
@@ -688,6 +694,16 @@ int hc_get_counters(hc_handle *h, uint64_t *out4)
     HIP_TRY(hipMemcpy(out4, h->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HC_OK;
 }
+
+#ifdef HC_PROFILE
+extern "C" int hc_debug_profile(hc_handle *h, uint64_t *out32)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out32, h->counters.p + 8, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+#endif
 
 int hc_synchronize(hc_handle *h)
 {
