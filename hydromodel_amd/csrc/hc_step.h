@@ -275,6 +275,18 @@ __device__ __forceinline__ void col_stats(bool hasU, bool hasD, double fnU, doub
     sc = fmax(fabs(sf), fabs(sn));
 }
 
+#ifdef HC_PROFILE
+#define HC_STAMP(slot)                                                   \
+    {                                                                    \
+        const unsigned long long now_ = clock64();                       \
+        if (lane == 0) prof_lds[prof_slot] += (unsigned)(now_ - prof_t); \
+        prof_t = now_;                                                   \
+        prof_slot = (slot);                                              \
+    }
+#else
+#define HC_STAMP(slot)
+#endif
+
 enum Phase {
     PH_F0 = 0, PH_F1, PH_JAC, PH_JAC_REDO, PH_NEWTON,
     C_JAC_FIN, C_STEP_BEGIN, C_STEP_TRY, C_NEWTON_BEGIN, C_NEWTON_FAIL, C_ERR_TEST, C_ACCEPT,
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     bool have_f = true;
                     if (phase == PH_F0 && have_f) {
                         have_f = false;
+                        HC_STAMP(PH_F0);
                         // BDF.__init__: f0 = fun(t0, y0); select_initial_step part 1
                         nfev++;
                         double y0v[CPL];
@@ -462,6 +475,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     }
                     if (phase == PH_F1 && have_f) {
                         have_f = false;
+                        HC_STAMP(PH_F1);
                         // select_initial_step part 2 (order = 1)
                         nfev++;
                         double df[CPL];
@@ -483,6 +497,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     }
                     if (phase == PH_NEWTON && have_f) {
                         have_f = false;
+                        HC_STAMP(PH_NEWTON);
                         // solve_bdf_system, iteration newton_k
                         nfev++;
                         bool fin = true;
@@ -499,8 +514,11 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             double dy[CPL];
 #pragma unroll
                             for (int c = 0; c < CPL; c++) dy[c] = vnode[c] ? cc * f[c] - psiv[c] - dd[c] : 0.0;
+                            HC_STAMP(20);
                             lu_solve<CPL>(F, dy, lane);
+                            HC_STAMP(21);
                             const double dy_norm = rms_ratio<CPL>(dy, scl, lane, D, inv_sqrt_d);
+                            HC_STAMP(22);
                             const bool have_rate = dy_norm_old >= 0.0;
                             const double rate = have_rate ? dy_norm / dy_norm_old : 0.0;
                             double rp = rate;
@@ -530,6 +548,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         }
                     }
                     if (phase == C_NEWTON_FAIL) {
+                        HC_STAMP(C_NEWTON_FAIL);
                         if (current_jac) {
                             h_abs *= 0.5;
                             change_D<CPL>(Dv, ru, order, 0.5, lane);
@@ -546,6 +565,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     }
                     if (phase == PH_JAC_REDO && have_f) {
                         have_f = false;
+                        HC_STAMP(PH_JAC_REDO);
                         // f = fun(y + h_new * [column small and in group g]); keep the new column where
                         // max_diff * scale_new < max_diff_new * scale  (common.py _sparse_num_jac)
                         __builtin_amdgcn_wave_barrier();
@@ -611,6 +631,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         }
                     }
                     if (phase == PH_JAC) {
+                        HC_STAMP(PH_JAC);
                         if (g < 0) {
                             // common.num_jac: step h per column from factor, f sign and |y|
 #pragma unroll
@@ -648,6 +669,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         }
                     }
                     if (phase == C_JAC_FIN) {
+                        HC_STAMP(C_JAC_FIN);
                         // _sparse_num_jac: per-column max |diff| (rows j-1, j, j+1), its scale, factor update,
                         // J = diff / h.  jac_stage 0 = first look, 1 = after the retry pass below.
                         __builtin_amdgcn_wave_barrier();
@@ -736,6 +758,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         }
                     }
                     if (phase == C_ERR_TEST) {
+                        HC_STAMP(C_ERR_TEST);
                         safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (double)(2 * NEWTON_MAXITER + n_iter);
                         const double ec = error_const_k(order);
                         double e[CPL];
@@ -756,6 +779,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         }
                     }
                     if (phase == C_ACCEPT) {
+                        HC_STAMP(C_ACCEPT);
                         n_equal++;
                         t = t_new;
                         nsteps++;
@@ -808,6 +832,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
 
                     }
                     if (phase == C_STEP_BEGIN) {
+                        HC_STAMP(C_STEP_BEGIN);
                         // _step_impl entry
                         min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
                         if (h_abs < min_step) {
@@ -819,6 +844,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         phase = C_STEP_TRY;
                     }
                     if (phase == C_STEP_TRY) {
+                        HC_STAMP(C_STEP_TRY);
                         if (h_abs < min_step) {
                             phase = C_FAIL;
                         } else {
@@ -850,8 +876,11 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         }
                     }
                     if (phase == C_NEWTON_BEGIN) {
+                        HC_STAMP(C_NEWTON_BEGIN);
                         if (!have_lu) {
+                            HC_STAMP(23);
                             lu_factor<CPL>(F, jl, jd, ju, cc, lane, D);
+                            HC_STAMP(C_NEWTON_BEGIN);
                             have_lu = 1;
                             nlu++;
                         }
