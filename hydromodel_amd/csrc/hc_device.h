@@ -133,8 +133,8 @@ __device__ __forceinline__ double fast_rcp(double b)
     r = fma(fma(-b, r, 1.0), r, r);
     return fma(fma(-b, r, 1.0), r, r);
 }
-// log(x) for finite x >= 1 (argument of the log-normal transform): fdlibm's e_log kernel, ~1 ulp
-__device__ __forceinline__ double log_ge1(double x)
+// log(x) for finite normal x > 0: fdlibm's e_log kernel, ~1 ulp, no special-case ladder
+__device__ __forceinline__ double log_pos(double x)
 {
     double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
@@ -251,7 +251,7 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
         // Lt = log(v/m^2 + 1)   (utilities.py:10-19 restructured: one log, one sqrt, one exp)
         const double var = P.sigma * (1.0 - s);
         const double t = fma(var, invm2, 1.0);
-        const double Lt = log_ge1(t);
+        const double Lt = log_pos(t);
         const double sig = sqrt_pos(Lt);
         kb = exp_mid(fma(sig, rnd, fma(-0.5, Lt, logm)));
         kb = noisec < 0.0 ? P.sat_soil : kb;   // cell in no layer: vrettas_fung.py:143

@@ -102,14 +102,40 @@ __device__ __forceinline__ double rms_ratio(const double (&x)[CPL], const double
         const double r = x[c] * is[c];
         acc += (lane * CPL + c < D) ? r * r : 0.0;
     }
-    return sqrt(wave_sum(acc)) * inv_sqrt_d;
+    return sqrt_pos(wave_sum(acc)) * inv_sqrt_d;
 }
 
-// bdf.py change_D: D[:order+1] = (R(order,factor) @ R(order,1)).T @ D[:order+1]
+// bdf.py change_D: D[:order+1] = (R(order,factor) @ R(order,1)).T @ D[:order+1].
+// R[i][j] = prod_{q=1..i} (q-1-factor*j)/q (R[0][j] = 1, R[i>0][0] = 0); lanes 0..35 build R and U = R(.,1)
+// in LDS, lanes 0..35 form RU, then every lane applies RU^T to its cells.
+template <int CPL, int ORDER>
+__device__ __forceinline__ void apply_RU(double *Dv, const double *ru, int lane)
+{
+    constexpr int SLOTS = WAVE * CPL;
+    double m[ORDER + 1][ORDER + 1];
+#pragma unroll
+    for (int a = 0; a <= ORDER; a++)
+#pragma unroll
+        for (int b = 0; b <= ORDER; b++) m[a][b] = ru[72 + a * 6 + b];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int slot = c * WAVE + lane;
+        double col[ORDER + 1];
+#pragma unroll
+        for (int k = 0; k <= ORDER; k++) col[k] = Dv[k * SLOTS + slot];
+#pragma unroll
+        for (int a = 0; a <= ORDER; a++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k <= ORDER; k++) s += m[k][a] * col[k];
+            Dv[a * SLOTS + slot] = s;
+        }
+    }
+}
+
 template <int CPL>
 __device__ __forceinline__ void change_D(double *Dv, double *ru, int order, double factor, int lane)
 {
-    constexpr int SLOTS = WAVE * CPL;
     const int i = lane / 6, j = lane % 6;
     double r = 1.0, u = 1.0;
     if (lane < 36) {
@@ -134,26 +160,12 @@ __device__ __forceinline__ void change_D(double *Dv, double *ru, int order, doub
         ru[72 + lane] = s;
     }
     __builtin_amdgcn_wave_barrier();
-    double m[6][6];
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-        for (int b = 0; b < 6; b++) m[a][b] = (a <= order && b <= order) ? ru[72 + a * 6 + b] : 0.0;
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        const int slot = c * WAVE + lane;
-        double col[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) col[k] = k <= order ? Dv[k * SLOTS + slot] : 0.0;
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-            if (a <= order) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) s += m[k][a] * col[k];
-                Dv[a * SLOTS + slot] = s;
-            }
-        }
+    switch (order) {
+        case 1: apply_RU<CPL, 1>(Dv, ru, lane); break;
+        case 2: apply_RU<CPL, 2>(Dv, ru, lane); break;
+        case 3: apply_RU<CPL, 3>(Dv, ru, lane); break;
+        case 4: apply_RU<CPL, 4>(Dv, ru, lane); break;
+        default: apply_RU<CPL, 5>(Dv, ru, lane); break;
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -500,17 +512,12 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         HC_STAMP(PH_NEWTON);
                         // solve_bdf_system, iteration newton_k
                         nfev++;
-                        bool fin = true;
-#pragma unroll
-                        for (int c = 0; c < CPL; c++) fin = fin && (!vnode[c] || isfinite(f[c]));
-                        if (newton_k == 0) {
+                        if (newton_k == 0 && !current_jac) {   // f(y_predict): base value of a Jacobian refresh
 #pragma unroll
                             for (int c = 0; c < CPL; c++) V[V_FP * SLOTS + c * WAVE + lane] = f[c];
                         }
                         bool converged = false, failed_newton = false;
-                        if (!__all(fin)) {
-                            failed_newton = true;
-                        } else {
+                        {
                             double dy[CPL];
 #pragma unroll
                             for (int c = 0; c < CPL; c++) dy[c] = vnode[c] ? cc * f[c] - psiv[c] - dd[c] : 0.0;
@@ -519,11 +526,15 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             HC_STAMP(21);
                             const double dy_norm = rms_ratio<CPL>(dy, scl, lane, D, inv_sqrt_d);
                             HC_STAMP(22);
+                            // scipy: `if not np.all(np.isfinite(f)): break`.  A non-finite f makes the solve and its
+                            // norm non-finite, and the iterate is left untouched either way.
                             const bool have_rate = dy_norm_old >= 0.0;
                             const double rate = have_rate ? dy_norm / dy_norm_old : 0.0;
                             double rp = rate;
                             for (int q = 1; q < NEWTON_MAXITER - newton_k; q++) rp *= rate;
-                            if (have_rate && (rate >= 1.0 || rp / (1.0 - rate) * dy_norm > NEWTON_TOL)) {
+                            // rate**(4-k) / (1 - rate) * dy_norm > tol, with 0 <= rate < 1 on the right-hand branch
+                            if (!(dy_norm < INFINITY) ||
+                                (have_rate && (rate >= 1.0 || rp * dy_norm > NEWTON_TOL * (1.0 - rate)))) {
                                 failed_newton = true;
                             } else {
 #pragma unroll
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                                     ycur[c] += dy[c];
                                     dd[c] += dy[c];
                                 }
-                                if (dy_norm == 0.0 || (have_rate && rate / (1.0 - rate) * dy_norm < NEWTON_TOL)) {
+                                if (dy_norm == 0.0 || (have_rate && rate * dy_norm < NEWTON_TOL * (1.0 - rate))) {
                                     converged = true;
                                 } else {
                                     dy_norm_old = dy_norm;
@@ -769,7 +780,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         }
                         error_norm = rms_ratio<CPL>(e, scl, lane, D, inv_sqrt_d);
                         if (error_norm > 1.0) {
-                            const double factor = fmax(0.2, safety * pow(error_norm, -1.0 / (double)(order + 1)));
+                            const double factor = fmax(0.2, safety * exp_mid(-log_pos(error_norm) / (double)(order + 1)));
                             h_abs *= factor;
                             change_D<CPL>(Dv, ru, order, factor, lane);
                             n_equal = 0;
@@ -815,7 +826,9 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             if (order < MAX_ORDER) np_ = rms_ratio<CPL>(ep, scl, lane, D, inv_sqrt_d);
                             // three pow() in three lanes at once
                             const double en = lane == 0 ? nm : (lane == 1 ? error_norm : np_);
-                            const double fk = pow(en, -1.0 / (double)(order + (lane < 3 ? lane : 2)));
+                            // error_norms ** (-1 / (order + k)), k = 0, 1, 2: three lanes at once
+                            double fk = exp_mid(-log_pos(en) / (double)(order + (lane < 3 ? lane : 2)));
+                            fk = en == 0.0 ? INFINITY : (en < INFINITY ? fk : (en == INFINITY ? 0.0 : en));
                             const double f0 = readlane_d(fk, 0), f1 = readlane_d(fk, 1), f2 = readlane_d(fk, 2);
                             int best = 0;
                             double fbest = f0;
