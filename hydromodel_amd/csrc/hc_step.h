@@ -170,6 +170,55 @@ __device__ __forceinline__ void change_D(double *Dv, double *ru, int order, doub
     __builtin_amdgcn_wave_barrier();
 }
 
+// bdf.py _step_impl after acceptance, for a compile-time order: D[order+2] = d - D[order+1]; D[order+1] = d;
+// D[k] += D[k+1] for k = order..0.  All rows are read before any is written (independent LDS reads).
+template <int CPL, int ORDER>
+__device__ __forceinline__ void accept_update(double *Dv, const double (&dd)[CPL], int lane, double (&d_ord)[CPL],
+                                              double (&d_ord2)[CPL])
+{
+    constexpr int SLOTS = WAVE * CPL;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int slot = c * WAVE + lane;
+        double r[ORDER + 2];
+#pragma unroll
+        for (int k = 0; k <= ORDER + 1; k++) r[k] = Dv[k * SLOTS + slot];
+        const double top2 = dd[c] - r[ORDER + 1];
+        Dv[(ORDER + 2) * SLOTS + slot] = top2;
+        Dv[(ORDER + 1) * SLOTS + slot] = dd[c];
+        double acc = dd[c];
+#pragma unroll
+        for (int k = ORDER; k >= 0; k--) {
+            acc += r[k];
+            Dv[k * SLOTS + slot] = acc;
+            if (k == ORDER) d_ord[c] = acc;
+        }
+        d_ord2[c] = top2;
+    }
+}
+// predictor: y_predict = sum_k D[k], psi = sum_{k>=1} gamma_k D[k] / alpha_order
+template <int CPL, int ORDER>
+__device__ __forceinline__ void predict(const double *Dv, int lane, double inv_alpha, double (&yp)[CPL],
+                                        double (&psiv)[CPL])
+{
+    constexpr int SLOTS = WAVE * CPL;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int slot = c * WAVE + lane;
+        double r[ORDER + 1];
+#pragma unroll
+        for (int k = 0; k <= ORDER; k++) r[k] = Dv[k * SLOTS + slot];
+        double sy = r[0], p = 0.0;
+#pragma unroll
+        for (int k = 1; k <= ORDER; k++) {
+            sy += r[k];
+            p += r[k] * GAMMA_TAB[k];
+        }
+        yp[c] = sy;
+        psiv[c] = p * inv_alpha;
+    }
+}
+
 // ---- lane-partitioned tridiagonal factorisation of A = I - cc*J -------------------------
 template <int CPL>
 struct TriLU {
@@ -794,17 +843,15 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         n_equal++;
                         t = t_new;
                         nsteps++;
+                        double d_ord[CPL], d_ord2[CPL];          // updated D[order], D[order+2]
 #pragma unroll
-                        for (int c = 0; c < CPL; c++) {
-                            const int slot = c * WAVE + lane;
-                            V[V_Y * SLOTS + slot] = ycur[c];        // sol.y[:, -1] so far
-                            Dv[(order + 2) * SLOTS + slot] = dd[c] - Dv[(order + 1) * SLOTS + slot];
-                            Dv[(order + 1) * SLOTS + slot] = dd[c];
-                            double acc = dd[c];
-                            for (int k = order; k >= 0; k--) {
-                                acc += Dv[k * SLOTS + slot];
-                                Dv[k * SLOTS + slot] = acc;
-                            }
+                        for (int c = 0; c < CPL; c++) V[V_Y * SLOTS + c * WAVE + lane] = ycur[c];   // sol.y[:, -1] so far
+                        switch (order) {
+                            case 1: accept_update<CPL, 1>(Dv, dd, lane, d_ord, d_ord2); break;
+                            case 2: accept_update<CPL, 2>(Dv, dd, lane, d_ord, d_ord2); break;
+                            case 3: accept_update<CPL, 3>(Dv, dd, lane, d_ord, d_ord2); break;
+                            case 4: accept_update<CPL, 4>(Dv, dd, lane, d_ord, d_ord2); break;
+                            default: accept_update<CPL, 5>(Dv, dd, lane, d_ord, d_ord2); break;
                         }
                         if (t == tf) {
                             phase = C_SUCCESS;
@@ -817,9 +864,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             const double ecp = order < MAX_ORDER ? error_const_k(order + 1) : 0.0;
 #pragma unroll
                             for (int c = 0; c < CPL; c++) {
-                                const int slot = c * WAVE + lane;
-                                em[c] = ecm * Dv[order * SLOTS + slot];
-                                ep[c] = ecp * Dv[(order + 2) * SLOTS + slot];
+                                em[c] = ecm * d_ord[c];
+                                ep[c] = ecp * d_ord2[c];
                             }
                             double nm = INFINITY, np_ = INFINITY;
                             if (order > 1) nm = rms_ratio<CPL>(em, scl, lane, D, inv_sqrt_d);
@@ -871,19 +917,15 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             const double h = t_new - t;
                             h_abs = fabs(h);
                             const double inv_alpha = 1.0 / alpha_k(order);
-#pragma unroll
-                            for (int c = 0; c < CPL; c++) {
-                                const int slot = c * WAVE + lane;
-                                double s = Dv[slot], p = 0.0;
-                                for (int k = 1; k <= order; k++) {
-                                    const double dk = Dv[k * SLOTS + slot];
-                                    s += dk;
-                                    p += dk * gamma_k(k);
-                                }
-                                yp[c] = s;
-                                scl[c] = 1.0 / (ATOL + RTOL * fabs(s));
-                                psiv[c] = p * inv_alpha;
+                            switch (order) {
+                                case 1: predict<CPL, 1>(Dv, lane, inv_alpha, yp, psiv); break;
+                                case 2: predict<CPL, 2>(Dv, lane, inv_alpha, yp, psiv); break;
+                                case 3: predict<CPL, 3>(Dv, lane, inv_alpha, yp, psiv); break;
+                                case 4: predict<CPL, 4>(Dv, lane, inv_alpha, yp, psiv); break;
+                                default: predict<CPL, 5>(Dv, lane, inv_alpha, yp, psiv); break;
                             }
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) scl[c] = 1.0 / (ATOL + RTOL * fabs(yp[c]));
                             cc = h / alpha_k(order);
                             phase = C_NEWTON_BEGIN;
                         }
