@@ -57,6 +57,7 @@ struct IoArgs {
     int *stats;               // [n_rows][N][6] or null
     double *psi_rows;         // [n_rows][N][D] or null
     unsigned long long *counters;   // [0] FD-Jacobian retry passes, [1] failed attempts, [2] loop-guard trips
+    unsigned long long *queue;      // member ticket of the persistent grid, zeroed before every launch
 };
 
 struct StepArgs {
@@ -366,9 +367,10 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     for (int k = threadIdx.x; k < NGTAB * SLOTS; k += WPB * WAVE) gtab[k] = A.gtab[k];
     __syncthreads();
 
+    // No barrier below this line: every wave is an independent worker.  The grid is persistent (one
+    // workgroup per CU); a wave that finishes its member takes the next one from a device-wide ticket,
+    // so members of unequal cost never leave SIMDs idle behind a slow neighbour.  Exit: ticket >= N.
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    const long long member = (long long)blockIdx.x * WPB + wave;
-    if (member >= A.n_members) return;          // no barrier below this line
     double *V = wave_base + (size_t)wave * (NVEC * SLOTS + WAVE_SCRATCH);
     double *ru = V + NVEC * SLOTS;
     double *row0 = ru + 108;                    // f_new[group][row 0], <= 16 groups
@@ -382,6 +384,16 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
 
+    for (;;) {
+    long long member;
+    {
+        const IoArgs io = load_const(A.io);
+        unsigned long long ticket = 0;
+        if (lane == 0) ticket = atomicAdd(io.queue, 1ull);
+        member = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ticket >> 32)) << 32) |
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)ticket));
+    }
+    if (member >= A.n_members) break;
     bool vnode[CPL];
     int gs[CPL], gp[CPL], gn[CPL];
 #pragma unroll
@@ -1015,8 +1027,10 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
 #ifdef HC_PROFILE
         __builtin_amdgcn_wave_barrier();
         if (lane < 32) atomicAdd(&io.counters[8 + lane], prof_lds[lane]);
+        if (lane < 32) prof_lds[lane] = 0;
 #endif
     }
+    }   // next member
 }
 
 }  // namespace hc

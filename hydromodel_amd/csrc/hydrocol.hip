@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -88,6 +89,7 @@ struct hc_handle {
     uint64_t seed = 0;
     int64_t member_offset = 0;
     int rows_per_launch = 48;
+    int n_cu = 256;
     double jac_reject = NUM_JAC_DIFF_REJECT;
 };
 
@@ -257,7 +259,10 @@ int launch_step_t(hc_handle *h, const StepArgs &A)
     const size_t lds = step_lds_bytes(CPL, WPB);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    const unsigned grid = (unsigned)((A.n_members + WPB - 1) / WPB);
+    // persistent grid: LDS admits one workgroup per CU; fewer workgroups when there are fewer members
+    const long long want = (A.n_members + WPB - 1) / WPB;
+    const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->n_cu);
+    HIP_TRY(hipMemsetAsync(h->counters.p + 63, 0, sizeof(unsigned long long), h->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * WAVE), lds, h->stream, A);
     HIP_TRY(hipGetLastError());
     return HC_OK;
@@ -342,6 +347,7 @@ int fill_args(hc_handle *h, StepArgs &A)
     io.member_offset = h->member_offset;
     io.seed = h->seed;
     io.counters = h->counters.p;
+    io.queue = h->counters.p + 63;
     return HC_OK;
 }
 
@@ -372,6 +378,11 @@ int hc_create(int device_ordinal, hc_handle **out)
     HIP_TRY(hipEventCreate(&h->ev1));
     if (h->counters.ensure(64) != HC_OK) return HC_ERR_DEVICE;
     HIP_TRY(hipMemset(h->counters.p, 0, 64 * sizeof(unsigned long long)));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     const char *rpl = getenv("HYDROCOL_ROWS_PER_LAUNCH");
     if (rpl && atoi(rpl) > 0) h->rows_per_launch = atoi(rpl);
     const char *jr = getenv("HYDROCOL_DEBUG_JAC_REJECT");   // test hook: exercises num_jac's retry branch
