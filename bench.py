@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     return ap.parse_args()
 
 
@@ -86,10 +87,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    n_dev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % n_dev                 # one rank per GPU; a gloo rehearsal may share a card
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    dev = torch.device("cuda", dev_index)
+    local_rank = dev_index
 
     from hydromodel_amd.digest import ColumnTables, ForcingDigest
     from hydromodel_amd.ensemble import EnsembleSimulation, allreduce_moments, spinup_on_gpu
@@ -129,7 +136,7 @@ def main():
         sim.advance(ROWS_PER_DAY)          # hc_step_rows synchronises the library's stream
     sync()
     elapsed = time.perf_counter() - t0
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
