@@ -130,3 +130,39 @@ def allreduce_moments(moments, device):
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+def parameter_sweep(params, data, well, points, n_members, n_rows, seed=0, device=0, rank=0, world=1):
+    """BASELINE config 5: a grid of (n, a0, psi_sat, ...) points x ``n_members`` realisations each.
+
+    ``points`` is a list of dicts ``{"Soil_Properties": {...}, "Hydraulic_Conductivity": {...}, ...}``
+    merged over ``params``.  Field capacity, wilting point, iPsi_50 and the spin-up equilibrium depend on
+    the point (porosity.py:172-181, simulation.py:339), so every point gets its own tables and its own
+    spin-up; whole points are dealt to ranks round-robin (rank r owns points r, r+world, ...), with no
+    communication.  Returns {point index: {"moments", "wtd_mean_cm", "wtd_std_cm", "psi0"}}.
+    """
+    import copy
+    from .digest import ColumnTables, ForcingDigest
+    out = {}
+    for k, override in enumerate(points):
+        if k % world != rank:
+            continue
+        p = copy.deepcopy(params)
+        for section, values in override.items():
+            if isinstance(values, dict):
+                p.setdefault(section, {}).update(values)
+            else:
+                p[section] = values
+        cols = ColumnTables(p, well)
+        forcing = ForcingDigest(p, data, cols)
+        sim = EnsembleSimulation(cols, forcing, n_members, seed=seed + 7919 * k, device=device)
+        done = 0
+        while done < n_rows:
+            n = min(48 * 8, n_rows - done)
+            sim.advance(n)
+            done += n
+        m = sim.moments()
+        mean_cm, std_cm = sim.wtd_mean_std(m)
+        out[k] = {"moments": m, "wtd_mean_cm": mean_cm, "wtd_std_cm": std_cm, "psi0": sim.psi0}
+        sim.close()
+    return out

@@ -517,3 +517,35 @@ def test_default_runs_never_take_the_retry_branch(gpu):
     c = st.counters()
     assert c["jac_retry"] == 0 and c["guard_trips"] == 0
     st.close()
+
+
+def test_parameter_sweep_points_are_independent_runs(gpu):
+    """Config 5 in miniature: 4 (n, a0, psi_sat) points x 32 members; a point of the sweep equals the same point run alone."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import EnsembleSimulation, parameter_sweep
+    from hydromodel_amd.synthetic import default_parameters
+    from helpers import WELLS, forcing_frame
+    params = default_parameters()
+    pts = [{"Soil_Properties": {"n": n, "a0": a0, "psi_sat": ps}}
+           for n, a0, ps in ((2.0, 0.009, -0.0047), (1.5, 0.003, -0.001), (3.0, 0.03, -1.0), (2.2, 0.012, -0.05))]
+    res = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, n_members=32, n_rows=48, seed=5)
+    assert sorted(res) == [0, 1, 2, 3]
+    for k in res:
+        m = res[k]["moments"]
+        assert np.array_equal(m[0, 1:49], np.full(48, 32)) and np.isfinite(res[k]["psi0"]).all()
+    assert not np.array_equal(res[0]["psi0"], res[2]["psi0"])          # the equilibrium depends on the point
+    # point 1 alone
+    import copy
+    p1 = copy.deepcopy(params)
+    p1["Soil_Properties"].update(pts[1]["Soil_Properties"])
+    cols = ColumnTables(p1, WELLS[200])
+    forcing = ForcingDigest(p1, forcing_frame(1), cols)
+    sim = EnsembleSimulation(cols, forcing, 32, seed=5 + 7919 * 1)
+    sim.advance(48)
+    assert np.array_equal(sim.moments(), res[1]["moments"])
+    sim.close()
+    # rank split: 2 "ranks" cover the grid exactly once
+    r0 = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, 32, 48, seed=5, rank=0, world=2)
+    r1 = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, 32, 48, seed=5, rank=1, world=2)
+    assert sorted(r0) == [0, 2] and sorted(r1) == [1, 3]
+    assert np.array_equal(r1[3]["moments"], res[3]["moments"])
