@@ -133,6 +133,15 @@ __device__ __forceinline__ double fast_rcp(double b)
     r = fma(fma(-b, r, 1.0), r, r);
     return fma(fma(-b, r, 1.0), r, r);
 }
+// value of lane (byte_addr / 4) mod 64 -- raw ds_bpermute, no index arithmetic.  Callers pass
+// (lane +- d) * 4 and mask the lanes whose source falls outside the wave themselves.
+__device__ __forceinline__ double bpermute_d(int byte_addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // log(x) for finite normal x > 0: fdlibm's e_log kernel, ~1 ulp, no special-case ladder
 __device__ __forceinline__ double log_pos(double x)
 {

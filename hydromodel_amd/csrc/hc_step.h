@@ -276,8 +276,9 @@ __device__ __forceinline__ void lu_factor(TriLU<CPL> &F, const double (&jl)[CPL]
 #pragma unroll
     for (int s = 0; s < 6; s++) {
         const int d = 1 << s;
-        double Bm = __shfl_up(B, d, WAVE), Um = __shfl_up(U, d, WAVE), Lm = __shfl_up(L, d, WAVE);
-        double Bp = __shfl_down(B, d, WAVE), Lp = __shfl_down(L, d, WAVE), Up = __shfl_down(U, d, WAVE);
+        const int am = (lane - d) * 4, ap = (lane + d) * 4;
+        double Bm = bpermute_d(am, B), Um = bpermute_d(am, U), Lm = bpermute_d(am, L);
+        double Bp = bpermute_d(ap, B), Lp = bpermute_d(ap, L), Up = bpermute_d(ap, U);
         const bool hm = lane >= d, hp = lane + d < WAVE;
         Bm = hm ? Bm : 1.0; Um = hm ? Um : 0.0; Lm = hm ? Lm : 0.0;
         Bp = hp ? Bp : 1.0; Lp = hp ? Lp : 0.0; Up = hp ? Up : 0.0;
@@ -303,7 +304,7 @@ __device__ __forceinline__ void lu_solve(const TriLU<CPL> &F, double (&x)[CPL], 
 #pragma unroll
     for (int s = 0; s < 6; s++) {
         const int d = 1 << s;
-        double Rm = __shfl_up(Rr, d, WAVE), Rp = __shfl_down(Rr, d, WAVE);
+        double Rm = bpermute_d((lane - d) * 4, Rr), Rp = bpermute_d((lane + d) * 4, Rr);
         Rm = lane >= d ? Rm : 0.0;
         Rp = lane + d < WAVE ? Rp : 0.0;
         Rr = Rr + F.al[s] * Rm + F.ga[s] * Rp;
