@@ -38,6 +38,9 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # half of the fetched bytes -- confirmed on a calibration dispatch that only loads and stores psi)
 # + WRITE_SIZE = (2 x 78 574.5 + 178 688) KiB / 65 536 members.
 PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 = (2 * 78574.5 + 178688.0) * 1024.0 / 65536.0
+# fp64 work per column-step at D=300 from rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 (wave instructions
+# per column-step: 2 977 / 4 314 / 8 913 / 840; x64 lanes, FMA = 2 flop) -- the secondary, honest roofline
+PMC_F64_FLOP_PER_COLUMN_STEP_D300 = (2977 + 4314 + 840 + 2 * 8913) * 64.0
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
 
 
@@ -177,6 +180,12 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "path is fp64-VALU/recurrence bound (SURVEY.md §8d): ~24 RHS evaluations per "
                              "column-step at ~10^2 flop per byte of state"},
+        "valu_f64": ({"achieved": value * ROWS_PER_DAY * PMC_F64_FLOP_PER_COLUMN_STEP_D300 / 1e12 / world,
+                      "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
+                      "frac": value * ROWS_PER_DAY * PMC_F64_FLOP_PER_COLUMN_STEP_D300 / 1e12 / world
+                      / FP64_VALU_PEAK_TFLOPS,
+                      "source": "fp64 instruction mix per column-step from rocprofv3 PMC (profiles/README.md)"}
+                     if D == 300 else None),
         "moments_allreduce_s": allreduce_s,
         "wtd_mean_cm_last_row": float(mean_cm[last_row]), "wtd_std_cm_last_row": float(std_cm[last_row]),
         "spinup_iterations": spin_iters,
