@@ -12,6 +12,7 @@ Usage:
     python tests/golden/make_golden.py static     # G1-G4,G6  (fast, ~1 min)
     python tests/golden/make_golden.py traj 101   # G5 trajectory, well 1 (D=101), ~8 min
     python tests/golden/make_golden.py traj 200   # G5 trajectory, synthetic D=200, ~8 min
+    python tests/golden/make_golden.py short      # first days of vanGenuchten / HLIFT / ET+LF-off runs, ~1 min
 
 Vector families:
   G1 static tables / forcing digest     G2 pointwise plugin calls, pressure_head, logN_rnd, find_wtd
@@ -396,6 +397,54 @@ def g5_trajectory(well_no, tmp):
     return out
 
 
+class _StopRun(Exception):
+    pass
+
+
+def g5_short(well_no, tmp, n_rows, model="vrettas_fung", flags=None):
+    """First n_rows rows of the year-long run (whole-year forcing file, run() interrupted): per-row input/output."""
+    sim, params, data = _setup(well_no, tmp, model=model, flags=flags)
+    m = sim.mData
+    pde = sim.pde_model
+    cls = type(pde)
+    orig_solve = cls.solve
+    rec = {"rows": [], "y0": [], "y1": [], "nin": [], "nout": [], "stats": []}
+
+    def solve_wrapped(self, t_span, y0, *args):
+        i = int(t_span[1])
+        if i > n_rows:
+            raise _StopRun()
+        a = args[0]
+        n_in = a["n_rnd"].copy()
+        y0c = y0.copy()
+        with _SolveRecorder() as r:
+            y1 = orig_solve(self, t_span, y0, *args)
+        rec["rows"].append(i)
+        rec["y0"].append(y0c)
+        rec["y1"].append(np.array(y1))
+        rec["nin"].append(n_in)
+        rec["nout"].append(a["n_rnd"].copy())
+        rec["stats"].append([sum(c[0] for c in r.calls), sum(c[1] for c in r.calls), sum(c[2] for c in r.calls),
+                             r.calls[-1][3], len(r.calls)])
+        return y1
+
+    cls.solve = solve_wrapped
+    old = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        sim.run()
+    except _StopRun:
+        pass
+    finally:
+        sys.stdout.close()
+        sys.stdout = old
+        cls.solve = orig_solve
+    return {"rows": np.array(rec["rows"]), "y0": np.array(rec["y0"]), "y1": np.array(rec["y1"]),
+            "nrnd_in": np.array(rec["nin"]), "nrnd_out": np.array(rec["nout"]),
+            "stats": np.array(rec["stats"], dtype=np.int32), "initial_cond": m["initial_cond"],
+            "flags": np.array([int(bool(m["sim_flags"][k])) for k in ("SPINUP", "ET", "LF", "HLIFT", "PREDICT")])}
+
+
 def _save(name, arrays):
     meta = json.dumps(VERSIONS)
     np.savez_compressed(HERE / name, _meta=np.array(meta), **arrays)
@@ -415,6 +464,10 @@ def main(argv):
         elif mode == "traj":
             well = int(argv[2])
             _save(f"g5_traj_{well}.npz", g5_trajectory(well, tmp))
+        elif mode == "short":
+            _save("g5s_vangenuchten_200.npz", g5_short(200, tmp, 480, model="vanGenuchten"))
+            _save("g5s_hlift_200.npz", g5_short(200, tmp, 240, flags={"HLIFT": True}))
+            _save("g5s_noet_nolf_300.npz", g5_short(300, tmp, 240, flags={"ET": False, "LF": False}))
         else:
             raise SystemExit(__doc__)
 

@@ -210,3 +210,30 @@ def test_rng_stream_plan():
     assert np.array_equal(rng.standard_normal(101), g["draw2"])
     k1 = np.random.default_rng(np.random.SeedSequence(911, spawn_key=(1,))).standard_normal(8)
     assert np.array_equal(k1, g["member1_first8"])
+
+
+SHORT_RUNS = [("g5s_vangenuchten_200.npz", 200, "vanGenuchten", 480),
+              ("g5s_hlift_200.npz", 200, "vrettas_fung", 240),
+              ("g5s_noet_nolf_300.npz", 300, "vrettas_fung", 240)]
+
+
+@pytest.mark.parametrize("fname,well,model,n_rows", SHORT_RUNS)
+def test_plugin_and_flag_variants_replay(fname, well, model, n_rows):
+    """First days of reference runs with the vanGenuchten plugin, with HLIFT on, with ET and LF off."""
+    g = golden(fname)
+    fl = g["flags"]
+    o, cols, forcing = _oracle(well, model, flags={"ET": bool(fl[1]), "LF": bool(fl[2]), "HLIFT": bool(fl[3])})
+    assert g["rows"].tolist() == list(range(1, n_rows + 1))
+    errs, same = [], 0
+    for k, i in enumerate(g["rows"]):
+        row = Oracle.row(forcing.precip[i], forcing.atm[i], forcing.daylight[i], forcing.wtd_obs[i])
+        y1, st, n_out, _ = o.solve_row(row, i - 1, i, g["y0"][k], g["nrnd_in"][k])
+        ref = g["y1"][k]
+        errs.append(np.max(np.abs(y1 - ref) / (1.0 + np.abs(ref))))
+        same += [st["nfev"], st["njev"], st["nlu"], st["nsteps"], st["attempts"]] == g["stats"][k].tolist()
+    errs = np.array(errs)
+    hlift = bool(fl[3])       # hydraulic-lift night rows are very stiff (~1000 RHS evaluations): chaotic in the last bits
+    assert same >= (0.8 if hlift else 0.9) * len(errs), (same, len(errs))
+    assert np.median(errs) < 1e-10
+    assert np.quantile(errs, 0.8 if hlift else 0.9) < 1e-5
+    assert errs.max() < (0.2 if hlift else 5e-2)
