@@ -68,15 +68,26 @@ constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 
               DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138, DPP_WAVE_SHL1 = 0x130;
 template <int N> struct dpp_row_shr { static constexpr int value = 0x110 + N; };
 
+// DPP move of a double where every lane without a source receives 0 (bound_ctrl): no `old` operand to
+// initialise, which saves two v_mov_b32 per step over dpp_d<>(v, 0.0)
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ double dpp_z(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 // wave-wide sum, result uniform (no LDS traffic: 6 DPP steps + readlane)
 __device__ __forceinline__ double wave_sum(double v)
 {
-    v += dpp_d<DPP_QUAD_XOR1>(v, 0.0);
-    v += dpp_d<DPP_QUAD_XOR2>(v, 0.0);
-    v += dpp_d<DPP_ROW_HALF_MIRROR>(v, 0.0);
-    v += dpp_d<DPP_ROW_MIRROR>(v, 0.0);
-    v += dpp_d<DPP_ROW_BCAST15, 0xa>(v, 0.0);
-    v += dpp_d<DPP_ROW_BCAST31, 0xc>(v, 0.0);
+    v += dpp_z<DPP_QUAD_XOR1>(v);
+    v += dpp_z<DPP_QUAD_XOR2>(v);
+    v += dpp_z<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_z<DPP_ROW_MIRROR>(v);
+    v += dpp_z<DPP_ROW_BCAST15, 0xa>(v);
+    v += dpp_z<DPP_ROW_BCAST31, 0xc>(v);
     return readlane_d(v, WAVE - 1);
 }
 __device__ __forceinline__ void wave_sum2(double &a, double &b)
@@ -88,13 +99,13 @@ __device__ __forceinline__ void wave_sum2(double &a, double &b)
 __device__ __forceinline__ double wave_excl_scan(double v, int lane)
 {
     (void)lane;
-    v += dpp_d<dpp_row_shr<1>::value>(v, 0.0);
-    v += dpp_d<dpp_row_shr<2>::value>(v, 0.0);
-    v += dpp_d<dpp_row_shr<4>::value>(v, 0.0);
-    v += dpp_d<dpp_row_shr<8>::value>(v, 0.0);
-    v += dpp_d<DPP_ROW_BCAST15, 0xa>(v, 0.0);
-    v += dpp_d<DPP_ROW_BCAST31, 0xc>(v, 0.0);
-    return dpp_d<DPP_WAVE_SHR1>(v, 0.0);
+    v += dpp_z<dpp_row_shr<1>::value>(v);
+    v += dpp_z<dpp_row_shr<2>::value>(v);
+    v += dpp_z<dpp_row_shr<4>::value>(v);
+    v += dpp_z<dpp_row_shr<8>::value>(v);
+    v += dpp_z<DPP_ROW_BCAST15, 0xa>(v);
+    v += dpp_z<DPP_ROW_BCAST31, 0xc>(v);
+    return dpp_z<DPP_WAVE_SHR1>(v);
 }
 // value of lane-1 / lane+1 (`fill` at the wave edge)
 __device__ __forceinline__ double shfl_up1(double v, int lane, double fill)
