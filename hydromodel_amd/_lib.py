@@ -34,7 +34,7 @@ class StepArgs(C.Structure):
     """hc_step_args"""
     _fields_ = [("row_begin", C.c_int64), ("n_rows", C.c_int64), ("spinup", C.c_int32),
                 ("accumulate_moments", C.c_int32), ("fresh_noise", _dp), ("wtd_out", _ip),
-                ("stats_out", _ip), ("psi_rows_out", _dp), ("kernel_ms", C.c_double),
+                ("stats_out", _ip), ("psi_rows_out", _dp), ("diag_out", _dp), ("kernel_ms", C.c_double),
                 ("launches", C.c_int64)]
 
 

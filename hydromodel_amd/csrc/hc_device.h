@@ -36,6 +36,7 @@ struct ColumnDev {
 struct RowDev {
     double precip, atm;
     int daylight, wtd_obs, spinup;
+    int diag;   // also integrate transpiration / lateral flow of the interior call (pde_model.arg_out)
 };
 
 // ---------------------------------------------------------------- wave primitives
@@ -325,11 +326,15 @@ __device__ __forceinline__ int deepest_true(const bool (&pred)[CPL])
 template <int CPL, bool SPECIAL>
 __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, const double *tab,
                                          int lane, const double (&y)[CPL], const double (&rnd)[CPL],
-                                         double (&f)[CPL], double *aux)
+                                         double (&f)[CPL], double *aux, double &diag_tr, double &diag_lf)
 {
     constexpr int SLOTS = WAVE * CPL;
     const int D = P.D;
     const double half = 0.5 * P.dz;
+    if (R.diag) {
+        diag_tr = 0.0;
+        diag_lf = 0.0;
+    }
     double ym[CPL], dym[CPL], th[CPL], Kc[CPL], Cc[CPL], fl[CPL], sk[CPL];
     const double y_top = readlane_d(y[0], 0);
     const double y_nf = shfl_down1(y[0], lane, 0.0);
@@ -446,6 +451,12 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                 const double tr_pot = fmin(R.atm, water_k) / tot_x;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) sk[c] = isr[c] ? -(tr_pot * x_out[c]) : sk[c];
+                if (R.diag) {   // richards_pde.py:380-381: sum(uptake) * dz of the interior call
+                    double s_u = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CPL; c++) s_u += isr[c] ? tr_pot * x_out[c] : 0.0;
+                    diag_tr = wave_sum(s_u) * P.dz;
+                }
             }
         }
         // (b) first-midpoint call: one cell normalised on its own
@@ -488,12 +499,15 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         wtd_est = wtd_est < k - 1 ? wtd_est : k - 1;
         const int wtd_obs = R.wtd_obs < k - 1 ? R.wtd_obs : k - 1;
         if (wtd_est < wtd_obs) {
+            double s_l = 0.0;
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
                 const int p = lane * CPL + c - 1;
                 const bool in = (p >= wtd_est) && (p < wtd_obs);
                 sk[c] = in ? fmin(-2.5e-4 * ym[c], sk[c]) : sk[c];
+                s_l += in ? fabs(sk[c]) : 0.0;
             }
+            if (R.diag) diag_lf = wave_sum(s_l) * P.dz;   // richards_pde.py:374,388
         }
     }
     // ---- top boundary, richards_pde.py:414-476 (computed in lane 63's spare slot)

@@ -56,6 +56,7 @@ struct IoArgs {
     unsigned short *wtd_u16;  // [n_rows][N]
     int *stats;               // [n_rows][N][6] or null
     double *psi_rows;         // [n_rows][N][D] or null
+    double *diag;             // [n_rows][N][2] transpiration, lateral flow of the row's last RHS evaluation, or null
     unsigned long long *counters;   // [0] FD-Jacobian retry passes, [1] failed attempts, [2] loop-guard trips
     unsigned long long *queue;      // member ticket of the persistent grid, zeroed before every launch
 };
@@ -427,8 +428,10 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
             R.daylight = io.daylight[row];
             R.wtd_obs = io.wtd_obs[row];
             R.spinup = A.spinup;
+            R.diag = io.diag != nullptr;
             refresh = !A.spinup && io.refresh[row];
         }
+        double diag_tr = 0.0, diag_lf = 0.0;
         const double t0 = A.spinup ? 0.0 : (double)(row - 1);
         const double tf = t0 + 1.0;
         int st_nfev = 0, st_njev = 0, st_nlu = 0, st_nsteps = 0, attempts = 0;
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     }
                     if (phase < C_SUCCESS) {
                         const ColumnDev P = load_const(A.P);
-                        rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr);
+                        rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf);
 #ifdef HC_PROFILE
                         const unsigned long long now = clock64();
                         if (lane == 0) prof_lds[16] += (unsigned)(now - prof_t);
@@ -1016,6 +1019,10 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 for (int c = 0; c < CPL; c++)
                     if (vnode[c])
                         io.psi_rows[((size_t)r * A.n_members + member) * D + lane * CPL + c] = skip ? 0.0 : yv[c];
+            }
+            if (io.diag && lane == 0) {
+                io.diag[((size_t)r * A.n_members + member) * 2 + 0] = skip ? 0.0 : diag_tr;
+                io.diag[((size_t)r * A.n_members + member) * 2 + 1] = skip ? 0.0 : diag_lf;
             }
         }
     }

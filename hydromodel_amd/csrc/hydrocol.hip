@@ -74,7 +74,7 @@ struct hc_handle {
     ColumnDev P{};
     int cpl = 0, wpb = 0, slots = 0;
     bool special = false;
-    DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d;
+    DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
     DevBuf<int> gtab, wtd_obs, draw_idx, stats, scratch_i;
     DevBuf<unsigned char> daylight, refresh;
     DevBuf<unsigned short> wtd_u16;
@@ -174,7 +174,9 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
     R.daylight = io.daylight[row];
     R.wtd_obs = io.wtd_obs[row];
     R.spinup = A.spinup;
+    R.diag = 0;
     double y[CPL], rnd[CPL], f[CPL];
+    double dtr = 0.0, dlf = 0.0;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const int i = lane * CPL + c;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
         idx = (i < D - 1) ? idx : 0;
         rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * nz[(idx % CPL) * WAVE + idx / CPL];
     }
-    rhs_eval<CPL, SPECIAL>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr);
+    rhs_eval<CPL, SPECIAL>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr, dtr, dlf);
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const int i = lane * CPL + c;
@@ -398,6 +400,7 @@ int hc_destroy(hc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     h->tab.release(); h->node_tabs.release(); h->precip.release(); h->atm.release(); h->psi.release();
     h->base.release(); h->nscale.release(); h->fresh.release(); h->psi_rows.release(); h->scratch_d.release();
+    h->diag.release();
     h->gtab.release(); h->wtd_obs.release(); h->draw_idx.release(); h->stats.release(); h->scratch_i.release();
     h->Pdev.release(); h->iodev.release();
     h->daylight.release(); h->refresh.release(); h->wtd_u16.release(); h->moments.release(); h->counters.release();
@@ -648,6 +651,7 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
         if (h->wtd_u16.ensure((size_t)chunk * N)) return HC_ERR_DEVICE;
         if (a->stats_out && h->stats.ensure((size_t)chunk * N * 6)) return HC_ERR_DEVICE;
         if (a->psi_rows_out && h->psi_rows.ensure((size_t)chunk * N * D)) return HC_ERR_DEVICE;
+        if (a->diag_out && h->diag.ensure((size_t)chunk * N * 2)) return HC_ERR_DEVICE;
         h->io_host.fresh = h->fresh.p;
         h->io_host.row_begin = row0;
         A.n_rows = chunk;
@@ -655,6 +659,7 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
         h->io_host.wtd_u16 = h->wtd_u16.p;
         h->io_host.stats = a->stats_out ? h->stats.p : nullptr;
         h->io_host.psi_rows = a->psi_rows_out ? h->psi_rows.p : nullptr;
+        h->io_host.diag = a->diag_out ? h->diag.p : nullptr;
         rc = push_io(h);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(h->ev0, h->stream));
@@ -680,6 +685,9 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
                                    hipMemcpyDeviceToHost, h->stream));
         if (a->psi_rows_out)
             HIP_TRY(hipMemcpyAsync(a->psi_rows_out + (size_t)done * N * D, h->psi_rows.p, (size_t)chunk * N * D * 8,
+                                   hipMemcpyDeviceToHost, h->stream));
+        if (a->diag_out)
+            HIP_TRY(hipMemcpyAsync(a->diag_out + (size_t)done * N * 2, h->diag.p, (size_t)chunk * N * 2 * 8,
                                    hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         float ms = 0.f;

@@ -7,10 +7,9 @@ same printed messages.  What differs is where the arithmetic runs: every ``Richa
 Randomness follows the reference exactly: ``default_rng(SeedSequence(seed))``, draw #0 for the
 spin-up, #1 for the base vector, one more per refresh row.
 
-``lateral_flow`` / ``transpiration`` are best-effort diagnostics in the reference (whatever the last
-interior ``pde_fun`` call of a row's last RHS evaluation left behind -- possibly a rejected Newton
-iterate).  They are not parity targets; this class returns zero series of the right
-length for them (SURVEY.md §8f2 lists the diagnostics kernel as a "next" row).
+``lateral_flow`` / ``transpiration`` are whatever the interior ``pde_fun`` call of a row's LAST RHS
+evaluation left in ``pde_model.arg_out`` (richards_pde.py:380-391, simulation.py:629-630; SURVEY.md §3.4);
+the kernel integrates exactly those two sums on the last evaluation of every row when asked to.
 """
 import json
 import time
@@ -92,6 +91,7 @@ class Simulation(object):
         wtd_est = np.zeros(T, dtype=int)
         abs_error = np.zeros(T)
         psi[0] = y0
+        transp, lateral = np.zeros(T - 1), np.zeros(T - 1)     # pde_model.arg_out after each solve (:629-630)
 
         st = EnsembleStepper(cols, forcing, 1, device=self.device)
         try:
@@ -113,7 +113,10 @@ class Simulation(object):
                 fresh = np.empty((n_fresh, 1, D))
                 for k in range(n_fresh):                              # :601 one draw per refresh row, in order
                     fresh[k, 0] = self.rng.standard_normal(D)
-                out = st.step_rows(row, n, fresh_noise=fresh, moments=False, want_wtd=True, want_psi=True)
+                out = st.step_rows(row, n, fresh_noise=fresh, moments=False, want_wtd=True, want_psi=True,
+                                   want_diag=True)
+                transp[row - 1:row - 1 + n] = out["diag"][:, 0, 0]
+                lateral[row - 1:row - 1 + n] = out["diag"][:, 0, 1]
                 psi[row:row + n] = out["psi"][:, 0, :]
                 wtd_est[row:row + n] = out["wtd"][:, 0]
                 abs_error[row:row + n] = np.abs(forcing.zwtd_cm[row:row + n] - z[wtd_est[row:row + n]])
@@ -142,8 +145,8 @@ class Simulation(object):
         self.output["theta_vol"] = theta_vol
         self.output["abs_error"] = abs_error
         self.output["wtd_est_cm"] = z[wtd_est]
-        self.output["lateral_flow"] = np.zeros(T - 1)
-        self.output["transpiration"] = np.zeros(T - 1)
+        self.output["lateral_flow"] = lateral
+        self.output["transpiration"] = transp
 
     def _diagnostics(self, psi_rows, noise_rows, theta_vol, k_hrc, k_bkg):
         """Plugin call at the nodes for a batch of stored rows (each row rides as one 'member')."""

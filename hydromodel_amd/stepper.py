@@ -110,7 +110,7 @@ class EnsembleStepper:
         return int(self.forcing.refresh[row_begin:row_begin + n_rows].sum())
 
     def step_rows(self, row_begin, n_rows, fresh_noise=None, spinup=False, moments=True,
-                  want_wtd=False, want_stats=False, want_psi=False):
+                  want_wtd=False, want_stats=False, want_psi=False, want_diag=False):
         a = L.StepArgs()
         a.row_begin, a.n_rows, a.spinup, a.accumulate_moments = int(row_begin), int(n_rows), int(spinup), int(moments)
         keep = []
@@ -131,6 +131,9 @@ class EnsembleStepper:
         if want_psi:
             out["psi"] = np.zeros((n_rows, self.N, self.D))
             a.psi_rows_out = L.dptr(out["psi"])
+        if want_diag:
+            out["diag"] = np.zeros((n_rows, self.N, 2))
+            a.diag_out = L.dptr(out["diag"])
         L.check(self.lib.hc_step_rows(self.h, C.byref(a)))
         self.last_kernel_ms, self.last_launches = a.kernel_ms, a.launches
         out["kernel_ms"], out["launches"] = a.kernel_ms, a.launches

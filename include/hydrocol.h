@@ -108,6 +108,9 @@ typedef struct {
     int32_t *wtd_out;       /* nullable: [n_rows][n_members] wtd_est index per row             */
     int32_t *stats_out;     /* nullable: [n_rows][n_members][6] nfev,njev,nlu,nsteps,attempts,refresh */
     double *psi_rows_out;   /* nullable: [n_rows][n_members][D] state after every row          */
+    double *diag_out;       /* nullable: [n_rows][n_members][2] = transpiration, lateral_flow as
+                               pde_model.arg_out holds them after the row's solve
+                               (src/richards_pde.py:380-391, src/simulation.py:629-630)        */
     double kernel_ms;       /* out: device time of the launch(es), HIP events on the stream    */
     int64_t launches;       /* out */
 } hc_step_args;

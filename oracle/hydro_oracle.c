@@ -223,6 +223,13 @@ static double root_efficiency(const ho_column *c, int off, int nr, const double 
     return water_k;
 }
 
+static __thread double g_last_arg_out[2] = {0.0, 0.0};
+void ho_last_arg_out(double *out2)
+{
+    out2[0] = g_last_arg_out[0];
+    out2[1] = g_last_arg_out[1];
+}
+
 /* ---- RichardsPDE.pde_fun, ref: richards_pde.py:172-395 ------------------------------- */
 static void pde_fun(const ho_column *c, const ho_row *r, int view, const double *y, const double *dydz,
                     const double *n_rnd, double *C, double *sink, double *flux, double *tr_lf)
@@ -289,6 +296,10 @@ static void pde_fun(const ho_column *c, const ho_row *r, int view, const double 
         tr_lf[0] = transp;
         tr_lf[1] = lat;
     }
+    /* ref: richards_pde.py:380-391 -- var_arg_out is overwritten by EVERY pde_fun call; Simulation.run reads
+     * it after solve() (simulation.py:629-630), i.e. it sees the interior call of the last RHS evaluation */
+    g_last_arg_out[0] = transp;
+    g_last_arg_out[1] = lat;
 }
 
 /* ---- RichardsPDE.bc_fun, ref: richards_pde.py:414-476 -> pL (qL = qR = 1, pR = 0) ---- */
@@ -871,6 +882,33 @@ void ho_run(const ho_column *c, int64_t T, const double *precip, const double *a
             p[4] = (int32_t)st.attempts;
             p[5] = refresh[i];
         }
+    }
+}
+
+/* same as ho_run, additionally recording transpiration / lateral_flow per row: diag [T][2] */
+void ho_run_diag(const ho_column *c, int64_t T, const double *precip, const double *atm,
+                 const uint8_t *daylight, const int32_t *wtd_obs, const uint8_t *refresh,
+                 int64_t row_begin, int64_t row_end, double *psi, double *base_noise, double *fresh,
+                 int32_t *wtd_est, double *diag)
+{
+    int D = c->dim_d;
+    int64_t k_fresh = 0;
+    double y1[HO_MAXD];
+    uint8_t sat[HO_MAXD];
+    (void)T;
+    for (int64_t i = row_begin; i < row_end; i++) {
+        if (i == 0 || wtd_obs[i] < 0) continue;
+        ho_row r = {precip[i], atm[i], daylight[i], wtd_obs[i], 0};
+        double *noise = base_noise;
+        if (refresh[i]) {
+            noise = fresh + k_fresh * D;
+            k_fresh++;
+        }
+        ho_solve_row(c, &r, (double)(i - 1), (double)i, psi, noise, y1, NULL, NULL, 0);
+        for (int k = 0; k < D; k++) sat[k] = y1[k] >= c->psi_sat;
+        if (wtd_est) wtd_est[i] = ho_find_wtd(sat, D);
+        memcpy(psi, y1, sizeof(double) * D);
+        ho_last_arg_out(diag + 2 * i);
     }
 }
 

@@ -84,6 +84,14 @@ void ho_run(const ho_column *c, int64_t T, const double *precip, const double *a
 int ho_spinup(const ho_column *c, const ho_row *row0, double zwtd0_cm, const double *z,
               double *psi, double *n_rnd, int max_iter);
 
+/* pde_model.arg_out as Simulation.run reads it after a solve: {transpiration, lateral_flow} of the interior
+ * pde_fun call of the LAST RHS evaluation (richards_pde.py:380-391, simulation.py:629-630) */
+void ho_last_arg_out(double *out2);
+void ho_run_diag(const ho_column *c, int64_t T, const double *precip, const double *atm,
+                 const uint8_t *daylight, const int32_t *wtd_obs, const uint8_t *refresh,
+                 int64_t row_begin, int64_t row_end, double *psi, double *base_noise, double *fresh,
+                 int32_t *wtd_est, double *diag);
+
 /* test hooks (num_jac retry branch) */
 void ho_debug_set_jac_reject(double v);
 long ho_debug_jac_retry_count(void);

@@ -75,6 +75,11 @@ def lib():
         L.ho_run.restype = None
         L.ho_spinup.argtypes = [C.POINTER(HoColumn), C.POINTER(HoRow), C.c_double, _dp, _dp, _dp, C.c_int]
         L.ho_spinup.restype = C.c_int
+        L.ho_last_arg_out.argtypes = [_dp]
+        L.ho_last_arg_out.restype = None
+        L.ho_run_diag.argtypes = [C.POINTER(HoColumn), C.c_int64, _dp, _dp, _bp, _ip, _bp, C.c_int64,
+                                  C.c_int64, _dp, _dp, _dp, _ip, _dp]
+        L.ho_run_diag.restype = None
         L.ho_debug_set_jac_reject.argtypes = [C.c_double]
         L.ho_debug_set_jac_reject.restype = None
         L.ho_debug_jac_retry_count.argtypes = []
@@ -160,6 +165,32 @@ class Oracle:
         M = self.D - 1
         return out, {"c": aux[:M], "s": aux[M:2 * M], "f": aux[2 * M:3 * M], "pL": aux[3 * M],
                      "tr_lf_first": aux[3 * M + 1:3 * M + 3], "tr_lf_int": aux[3 * M + 3:3 * M + 5]}
+
+    @staticmethod
+    def last_arg_out():
+        """(transpiration, lateral_flow) left behind by the last RHS evaluation on this thread."""
+        out = np.zeros(2)
+        lib().ho_last_arg_out(_d(out))
+        return out
+
+    def run_diag(self, forcing, psi0, base_noise, fresh, row_begin=1, row_end=None):
+        """Row loop recording [T][2] = transpiration, lateral_flow per row (simulation.py:629-630)."""
+        T = forcing.dim_t
+        row_end = T if row_end is None else row_end
+        psi = np.array(psi0, dtype=np.float64)
+        base = np.array(base_noise, dtype=np.float64)
+        fresh = np.array(fresh, dtype=np.float64).reshape(-1, self.D)
+        wtd = np.zeros(T, dtype=np.int32)
+        diag = np.zeros((T, 2))
+        precip = np.ascontiguousarray(forcing.precip, dtype=np.float64)
+        atm = np.ascontiguousarray(forcing.atm, dtype=np.float64)
+        day = np.ascontiguousarray(forcing.daylight, dtype=np.uint8)
+        wobs = np.ascontiguousarray(forcing.wtd_obs, dtype=np.int32)
+        refr = np.ascontiguousarray(forcing.refresh, dtype=np.uint8)
+        lib().ho_run_diag(C.byref(self.c), T, _d(precip), _d(atm), day.ctypes.data_as(_bp),
+                          wobs.ctypes.data_as(_ip), refr.ctypes.data_as(_bp), row_begin, row_end, _d(psi),
+                          _d(base), _d(fresh) if fresh.size else None, wtd.ctypes.data_as(_ip), _d(diag))
+        return {"psi": psi, "wtd_est": wtd, "diag": diag}
 
     def solve_row(self, row, t0, t1, y0, n_rnd, cap_steps=0):
         """Returns (y1, stats dict, n_rnd after the in-place damping, accepted time points)."""

@@ -341,6 +341,13 @@ def g5_trajectory(well_no, tmp):
         a = args[0]
         n_in = a["n_rnd"].copy()
         y0c = y0.copy()
+        f0_rec = None
+        if i in rows_full:
+            # RHS at the row's start state, evaluated BEFORE the solve so that pde.arg_out (read by
+            # Simulation.run after the solve) is left as the solve itself leaves it
+            probe = dict(a)
+            probe["n_rnd"] = n_in.copy()
+            f0_rec = pde(float(t_span[0]), y0c.copy(), probe)
         with _SolveRecorder() as rec:
             y1 = orig_solve(pde, t_span, y0, *args)
         last = rec.calls[-1]
@@ -356,9 +363,7 @@ def g5_trajectory(well_no, tmp):
             rec_y1.append(np.array(y1))
             rec_nin.append(n_in)
             rec_nout.append(a["n_rnd"].copy())
-            flags_dummy = dict(a)
-            flags_dummy["n_rnd"] = n_in.copy()
-            rec_f0.append(pde(float(t_span[0]), y0c.copy(), flags_dummy))
+            rec_f0.append(f0_rec if f0_rec is not None else np.full(y0c.shape, np.nan))
             ts = last[5]
             pad = np.full(64, np.nan)
             pad[:min(64, ts.size)] = ts[:64]

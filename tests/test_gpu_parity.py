@@ -583,3 +583,59 @@ def test_plugin_and_flag_variants_replay_reference_rows(gpu, fname, well, model,
     assert np.quantile(errs, 0.7 if hlift else 0.9) < 1e-4
     assert errs.max() < (0.3 if hlift else 5e-2)
     st.close()
+
+
+# ------------------------------------------------------------------------------- §8(f2) diagnostics
+@pytest.mark.parametrize("well", [1, 200])
+def test_row_diagnostics_match_oracle_and_reference(gpu, well):
+    """transpiration / lateral_flow = pde_model.arg_out after the row's solve (simulation.py:629-630):
+    the two integrals of the interior pde_fun call of the row's LAST RHS evaluation."""
+    _, cols, forcing = digest(well)
+    g = golden(f"g5_traj_{well}.npz")
+    stats = g["per_row_stats"]
+    o = _oracle(cols, forcing)
+    st = gpu.EnsembleStepper(cols, forcing, 1)
+    e_or, e_ref, n_day, n_lf = [], [], 0, 0
+    for k, i in enumerate(g["rec_rows"]):
+        if stats[i, 4] > 1 or i < 1:
+            continue
+        y0, nin = g["rec_y0"][k], g["rec_nrnd_in"][k]
+        refresh = bool(forcing.refresh[i])
+        st.set_state(y0[None, :])
+        st.set_noise_host(nin[None, :])
+        fresh = nin[None, None, :] if refresh else np.zeros((0,))
+        out = st.step_rows(int(i), 1, fresh_noise=fresh, want_stats=True, want_diag=True)
+        _, so, _, _ = o.solve_row(_row(forcing, i), i - 1, i, y0, nin.copy())
+        d_or = o.last_arg_out()
+        d = out["diag"][0, 0]
+        if out["stats"][0, 0, 0] == so["nfev"]:
+            e_or.append(np.max(np.abs(d - d_or) / (1e-6 + np.abs(d_or))))
+        ref = np.array([g["transpiration"][i - 1], g["lateral_flow"][i - 1]])
+        if out["stats"][0, 0, 0] == stats[i, 0]:
+            e_ref.append(np.max(np.abs(d - ref) / (1e-6 + np.abs(ref))))
+        n_day += d[0] > 0
+        n_lf += d[1] > 0
+    assert len(e_or) > 250 and len(e_ref) > 250
+    assert n_day > 50 and n_lf > 20          # both branches exercised
+    assert np.median(e_or) < 1e-10 and max(e_or) < 1e-5, (np.median(e_or), max(e_or))
+    assert np.median(e_ref) < 1e-10 and max(e_ref) < 1e-5, (np.median(e_ref), max(e_ref))
+    st.close()
+
+
+def test_diagnostics_off_and_on_give_the_same_states(gpu):
+    """Asking for the diagnostics must not change one bit of the trajectory."""
+    _, cols, forcing = digest(200)
+    g = golden("g5_traj_200.npz")
+    res = []
+    for want in (False, True):
+        st = gpu.EnsembleStepper(cols, forcing, 5)
+        st.set_state(g["initial_cond"])
+        st.set_noise_philox(11)
+        out = st.step_rows(1, 48, want_wtd=True, want_diag=want)
+        res.append((st.get_state(), out["wtd"], out.get("diag")))
+        st.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    d = res[1][2]
+    assert d.shape == (48, 5, 2) and (d >= 0).all() and d[:, :, 0].max() > 0
+    night = ~forcing.daylight[1:49].astype(bool)
+    assert (d[night, :, 0] == 0).all()      # ET acts in daylight only (richards_pde.py:258)

@@ -99,3 +99,17 @@ def test_cli_ensemble_block(tmp_path, monkeypatch, capsys):
     assert int(data["members"]) == 256 and int(data["rows"]) == 96
     assert np.array_equal(data["moments"][0, 1:97], np.full(96, 256))
     assert np.all(np.isfinite(data["wtd_mean_cm"][1:97]))
+
+
+def test_year_long_diagnostics_track_the_reference(year_run):
+    """transpiration / lateral_flow (simulation.py:629-630) over the same 17 519 solves.  Transpiration is
+    demand-limited at this site, so it is insensitive to the chaotic last bits; lateral flow follows the
+    water table and inherits its drift."""
+    g = golden("g5_traj_1.npz")
+    out = year_run.output
+    tr, lf = out["transpiration"], out["lateral_flow"]
+    assert np.max(np.abs(tr[:48] - g["transpiration"][:48])) < 1e-12
+    assert abs(tr.sum() / g["transpiration"].sum() - 1) < 1e-6
+    assert np.max(np.abs(lf[:48] - g["lateral_flow"][:48]) / (1e-6 + g["lateral_flow"][:48])) < 5e-3
+    assert abs(lf.sum() / g["lateral_flow"].sum() - 1) < 0.03
+    assert np.corrcoef(lf, g["lateral_flow"])[0, 1] > 0.999

@@ -125,7 +125,7 @@ def test_trajectory_rows_replay(well):
     g = golden(f"g5_traj_{well}.npz")
     stats = g["per_row_stats"]
     rows = g["rec_rows"]
-    same_stats, errs, failing = 0, [], 0
+    same_stats, errs, failing, diag_errs = 0, [], 0, []
     for k, i in enumerate(rows):
         row = Oracle.row(forcing.precip[i], forcing.atm[i], forcing.daylight[i], forcing.wtd_obs[i])
         y1, st, n_out, _ = o.solve_row(row, i - 1, i, g["rec_y0"][k], g["rec_nrnd_in"][k])
@@ -133,6 +133,9 @@ def test_trajectory_rows_replay(well):
         errs.append(np.max(np.abs(y1 - ref) / (1.0 + np.abs(ref))))
         ok = (st["nfev"], st["njev"], st["nlu"], st["attempts"]) == tuple(stats[i, [0, 1, 2, 4]])
         same_stats += ok
+        if ok:   # pde_model.arg_out after the solve (simulation.py:629-630)
+            ref_d = np.array([g["transpiration"][i - 1], g["lateral_flow"][i - 1]])
+            diag_errs.append(np.max(np.abs(Oracle.last_arg_out() - ref_d) / (1e-6 + np.abs(ref_d))))
         if stats[i, 4] > 1:
             failing += 1
         elif ok:
@@ -142,6 +145,8 @@ def test_trajectory_rows_replay(well):
     assert np.median(errs) < 1e-12
     assert np.quantile(errs, 0.95) < 1e-6
     assert errs.max() < 0.1                       # failing (retried) rows are chaotic
+    diag_errs = np.array(diag_errs)
+    assert np.median(diag_errs) < 1e-12 and diag_errs.max() < 1e-5, (np.median(diag_errs), diag_errs.max())
     if well == 1:
         assert failing >= 10                      # the x0.8 retry path is exercised
 
