@@ -8,7 +8,7 @@ unknown keys, only membership of the 12 is checked):
 
 * ``--seed`` / JSON ``"Seed"``: seeds ``Simulation(name, seed)``; the reference's CLI cannot be seeded.
 * JSON ``"Ensemble": {"Members": N, "Seed": s, "Days": d}``: run N stochastic members with in-kernel
-  Philox noise and write the per-row water-table mean / sigma to ``<Output_Name>_ensemble.npz``.
+  Philox noise and write the per-row water-table mean / sigma to ``<Output_Name>_ensemble.h5``.
 """
 import sys
 from pathlib import Path
@@ -86,9 +86,16 @@ def _run_ensemble(params, water_data, output_name, ens, device):
         print(f" [Ensemble x{n_members}] {done} rows done")
     moments = sim.moments()
     mean_cm, std_cm = sim.wtd_mean_std(moments)
-    out = Path(output_name.strip().replace(" ", "_") + "_ensemble.npz")
-    np.savez_compressed(out, moments=moments, wtd_mean_cm=mean_cm, wtd_std_cm=std_cm, rows=np.array(rows),
-                        members=np.array(n_members), initial_cond=sim.psi0)
+    from . import hdf5io
+    arrays = dict(moments=moments, wtd_mean_cm=mean_cm, wtd_std_cm=std_cm, rows=np.array(rows),
+                  members=np.array(n_members), initial_cond=sim.psi0)
+    stem = output_name.strip().replace(" ", "_") + "_ensemble"
+    if hdf5io.available():      # same container as Simulation.saveResults (simulation.py:697-706)
+        out = Path(stem + ".h5")
+        hdf5io.write(out, arrays)
+    else:
+        out = Path(stem + ".npz")
+        np.savez_compressed(out, **arrays)
     print(f" Saving the ensemble water-table statistics to: {out}")
     sim.close()
 

@@ -18,6 +18,7 @@ from pathlib import Path
 import numpy as np
 from numpy.random import SeedSequence, default_rng
 
+from . import hdf5io
 from .digest import ColumnTables, ForcingDigest, load_site_well
 from .ensemble import spinup_on_gpu
 from .stepper import EnsembleStepper
@@ -161,21 +162,18 @@ class Simulation(object):
 
     # ------------------------------------------------------------------ results
     def saveResults(self):
-        """simulation.py:674-711: one gzip dataset per key in <name>.h5 (``.npz`` when h5py is absent)."""
+        """simulation.py:674-711: one gzip dataset per key in <name>.h5, written through libhdf5
+        (hdf5io.py; ``.npz`` only when no HDF5 library can be loaded)."""
         if not self.output:
             print(f" {self.__class__.__name__}: Simulation data structure 'output' is empty.")
             return
         stem = self.name.strip().replace(" ", "_")
-        try:
-            import h5py
-        except ImportError:
-            print(f" Saving the results to: {self.name}.npz (h5py is not installed)")
+        if not hdf5io.available():
+            print(f" Saving the results to: {self.name}.npz (no HDF5 library found)")
             np.savez_compressed(Path(stem + ".npz"), **self.output)
             return
         print(f" Saving the results to: {self.name}.h5")
-        with h5py.File(Path(stem + ".h5"), "w") as out_file:
-            for key, val in self.output.items():
-                out_file.create_dataset(key, data=val, shape=val.shape, compression="gzip")
+        hdf5io.write(Path(stem + ".h5"), self.output, compression="gzip")
 
 
 def loadResults(filename=None):
@@ -186,9 +184,7 @@ def loadResults(filename=None):
     if path.suffix == ".npz":
         with np.load(path) as data:
             return {k: np.array(data[k]) for k in data.files}
-    import h5py
-    with h5py.File(path, "r") as input_file:
-        return {key: np.array(input_file[key]) for key in input_file}
+    return hdf5io.read(path)
 
 
 def dump_json(obj, path):

@@ -81,9 +81,12 @@ def test_cli_end_to_end(tmp_path, monkeypatch, capsys):
                 " Simulation completed."):
         assert msg in text, msg
     files = list(tmp_path.glob("Sim_00.*"))
-    assert len(files) == 1
+    assert [f.name for f in files] == ["Sim_00.h5"]          # simulation.py:693
     data = loadResults(files[0])
-    assert data["psi_press"].shape == (17520, 101)
+    assert sorted(data) == sorted(["K_hrc", "K_bkg", "S_eff", "psi_press", "theta_vol", "abs_error",
+                                   "wtd_est_cm", "lateral_flow", "transpiration"])
+    assert data["psi_press"].shape == (17520, 101) and data["psi_press"].dtype == np.float64
+    assert data["transpiration"].shape == (17519,) and data["transpiration"].max() > 0
 
 
 def test_cli_ensemble_block(tmp_path, monkeypatch, capsys):
@@ -95,7 +98,8 @@ def test_cli_ensemble_block(tmp_path, monkeypatch, capsys):
     (tmp_path / "p.json").write_text(json.dumps(params))
     monkeypatch.chdir(tmp_path)
     cli.run_cli(["berkeley_hydro_main.py", "--params", str(tmp_path / "p.json")])
-    data = np.load(tmp_path / "Sim_00_ensemble.npz")
+    from hydromodel_amd.simulation import loadResults
+    data = loadResults(tmp_path / "Sim_00_ensemble.h5")
     assert int(data["members"]) == 256 and int(data["rows"]) == 96
     assert np.array_equal(data["moments"][0, 1:97], np.full(96, 256))
     assert np.all(np.isfinite(data["wtd_mean_cm"][1:97]))
