@@ -91,10 +91,24 @@ __device__ __forceinline__ double wave_sum(double v)
     v += dpp_z<DPP_ROW_BCAST31, 0xc>(v);
     return readlane_d(v, WAVE - 1);
 }
+// two sums at once: the chains are written step by step so that each one fills the other's DPP wait states
 __device__ __forceinline__ void wave_sum2(double &a, double &b)
 {
-    a = wave_sum(a);
-    b = wave_sum(b);
+    double u = a, v = b;
+    u += dpp_z<DPP_QUAD_XOR1>(u);
+    v += dpp_z<DPP_QUAD_XOR1>(v);
+    u += dpp_z<DPP_QUAD_XOR2>(u);
+    v += dpp_z<DPP_QUAD_XOR2>(v);
+    u += dpp_z<DPP_ROW_HALF_MIRROR>(u);
+    v += dpp_z<DPP_ROW_HALF_MIRROR>(v);
+    u += dpp_z<DPP_ROW_MIRROR>(u);
+    v += dpp_z<DPP_ROW_MIRROR>(v);
+    u += dpp_z<DPP_ROW_BCAST15, 0xa>(u);
+    v += dpp_z<DPP_ROW_BCAST15, 0xa>(v);
+    u += dpp_z<DPP_ROW_BCAST31, 0xc>(u);
+    v += dpp_z<DPP_ROW_BCAST31, 0xc>(v);
+    a = readlane_d(u, WAVE - 1);
+    b = readlane_d(v, WAVE - 1);
 }
 // exclusive prefix sum across lanes (Hillis-Steele inside 16-lane rows, then row broadcasts)
 __device__ __forceinline__ double wave_excl_scan(double v, int lane)
@@ -107,6 +121,27 @@ __device__ __forceinline__ double wave_excl_scan(double v, int lane)
     v += dpp_z<DPP_ROW_BCAST15, 0xa>(v);
     v += dpp_z<DPP_ROW_BCAST31, 0xc>(v);
     return dpp_z<DPP_WAVE_SHR1>(v);
+}
+// exclusive prefix sum of `scan` (its grand total comes for free from lane 63) and the plain sum of `sum`,
+// interleaved like wave_sum2
+__device__ __forceinline__ void wave_scan_and_sum(double &scan, double &scan_total, double &sum)
+{
+    double v = scan, u = sum;
+    v += dpp_z<dpp_row_shr<1>::value>(v);
+    u += dpp_z<DPP_QUAD_XOR1>(u);
+    v += dpp_z<dpp_row_shr<2>::value>(v);
+    u += dpp_z<DPP_QUAD_XOR2>(u);
+    v += dpp_z<dpp_row_shr<4>::value>(v);
+    u += dpp_z<DPP_ROW_HALF_MIRROR>(u);
+    v += dpp_z<dpp_row_shr<8>::value>(v);
+    u += dpp_z<DPP_ROW_MIRROR>(u);
+    v += dpp_z<DPP_ROW_BCAST15, 0xa>(v);
+    u += dpp_z<DPP_ROW_BCAST15, 0xa>(u);
+    v += dpp_z<DPP_ROW_BCAST31, 0xc>(v);
+    u += dpp_z<DPP_ROW_BCAST31, 0xc>(u);
+    scan_total = readlane_d(v, WAVE - 1);
+    sum = readlane_d(u, WAVE - 1);
+    scan = dpp_z<DPP_WAVE_SHR1>(v);
 }
 // value of lane-1 / lane+1 (`fill` at the wave edge)
 __device__ __forceinline__ double shfl_up1(double v, int lane, double fill)
@@ -264,8 +299,9 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
         pfac = pow(1.0 + pow(ap, P.n), -P.m);
     double q = fma(delta, pfac, P.theta_res);
     q = sat ? por : q;
-    // a true division: 1 - s is ill-conditioned near saturation, a 1-ulp reciprocal shows up in K_bkg
-    double s = (q - P.theta_res) / delta;
+    // a true division (1 - s is ill-conditioned near saturation, a 1-ulp reciprocal shows up in K_bkg):
+    // fast_div is the compiler's own f64 division sequence minus the exponent scaling / fix-up steps
+    double s = fast_div(q - P.theta_res, delta);
     s = fmin(fmax(s, 0.0), 1.0);
     if (SPECIAL || P.model == 0) {
         // K_bkg = exp(log(m^2/sqrt(v+m^2)) + sqrt(log(v/m^2+1))*rnd)  ==  exp(log m - Lt/2 + sqrt(Lt)*rnd),
@@ -295,9 +331,123 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
     }
     double c = P.mn_alpha * delta * s3 * apn;
     // saturated, below epsilon, NaN or infinite -> epsilon (vrettas_fung.py:243-249)
-    c = (!sat && c >= P.epsilon && c < INFINITY) ? c : P.epsilon;
+    c = (int(!sat) & int(c >= P.epsilon) & int(c < INFINITY)) ? c : P.epsilon;   // no short-circuit: no branch
     theta = q;
     C = c;
+}
+
+// The special-exponent cell model (n = 2, m = 1/2, lambda = 1; model_cell<true>) for the N cells a lane owns,
+// written "vertically": every statement is applied to all N cells before the next one, so that the N
+// independent dependency chains are interleaved in program order.  With one wave per SIMD nothing else hides
+// the latency of a dependent fp64 instruction, and the compiler does not interleave the chains by itself.
+// Same operations in the same order per cell as model_cell<true>.
+#define HC_V(...)                         \
+    _Pragma("unroll") for (int c = 0; c < N; c++) { __VA_ARGS__; }
+template <int N>
+__device__ __forceinline__ void model_cells_special(const ColumnDev &P, const double (&psi)[N], const double (&por)[N],
+                                                    const double (&logm)[N], const double (&invm2)[N],
+                                                    const double (&noisec)[N], const double (&rnd)[N],
+                                                    double (&theta)[N], double (&K)[N], double (&C)[N],
+                                                    double (&kbo)[N], double (&pfac)[N])
+{
+    double delta[N], ap[N], a[N], b[N], d[N], e[N], g[N], h[N], s[N], Lt[N], f[N], z[N], w[N], t1[N], t2[N], dk[N];
+    bool sat[N], lo[N];
+    int ex[N];
+    HC_V(delta[c] = por[c] - P.theta_res)
+    HC_V(sat[c] = psi[c] >= P.psi_sat)
+    HC_V(ap[c] = P.alpha * fabs(psi[c]))
+    // pfac = rsqrt_ge1(1 + ap^2)
+    HC_V(a[c] = fma(ap[c], ap[c], 1.0))
+    HC_V(b[c] = __builtin_amdgcn_rsq(a[c]))
+    HC_V(d[c] = -a[c] * b[c])
+    HC_V(e[c] = fma(d[c], b[c], 1.0))
+    HC_V(d[c] = b[c] * e[c])
+    HC_V(e[c] = fma(e[c], 0.375, 0.5))
+    HC_V(pfac[c] = fma(d[c], e[c], b[c]))
+    HC_V(a[c] = fma(delta[c], pfac[c], P.theta_res))
+    HC_V(theta[c] = sat[c] ? por[c] : a[c])
+    // s = (theta - theta_res) / delta
+    HC_V(a[c] = theta[c] - P.theta_res)
+    HC_V(b[c] = __builtin_amdgcn_rcp(delta[c]))
+    HC_V(d[c] = fma(-delta[c], b[c], 1.0))
+    HC_V(b[c] = fma(d[c], b[c], b[c]))
+    HC_V(d[c] = fma(-delta[c], b[c], 1.0))
+    HC_V(b[c] = fma(d[c], b[c], b[c]))
+    HC_V(d[c] = a[c] * b[c])
+    HC_V(e[c] = fma(-delta[c], d[c], a[c]))
+    HC_V(s[c] = fma(e[c], b[c], d[c]))
+    HC_V(s[c] = fmin(fmax(s[c], 0.0), 1.0))
+    // t = 1 + sigma (1 - s) / m^2;  Lt = log_pos(t)
+    HC_V(a[c] = P.sigma * (1.0 - s[c]))
+    HC_V(a[c] = fma(a[c], invm2[c], 1.0))
+    HC_V(b[c] = __builtin_amdgcn_frexp_mant(a[c]))
+    HC_V(ex[c] = __builtin_amdgcn_frexp_exp(a[c]))
+    HC_V(lo[c] = b[c] < 0.70710678118654752440)
+    HC_V(b[c] = lo[c] ? b[c] + b[c] : b[c])
+    HC_V(ex[c] = lo[c] ? ex[c] - 1 : ex[c])
+    HC_V(f[c] = b[c] - 1.0)
+    HC_V(a[c] = 2.0 + f[c])
+    HC_V(b[c] = __builtin_amdgcn_rcp(a[c]))
+    HC_V(d[c] = fma(-a[c], b[c], 1.0))
+    HC_V(b[c] = fma(d[c], b[c], b[c]))
+    HC_V(d[c] = fma(-a[c], b[c], 1.0))
+    HC_V(b[c] = fma(d[c], b[c], b[c]))
+    HC_V(d[c] = f[c] * b[c])
+    HC_V(e[c] = fma(-a[c], d[c], f[c]))
+    HC_V(g[c] = fma(e[c], b[c], d[c]))                  // g = s of fdlibm's log kernel
+    HC_V(z[c] = g[c] * g[c])
+    HC_V(w[c] = z[c] * z[c])
+    HC_V(t1[c] = fma_s(w[c], 1.531383769920937332e-01, 2.222219843214978396e-01))
+    HC_V(t2[c] = fma_s(w[c], 1.479819860511658591e-01, 1.818357216161805012e-01))
+    HC_V(t1[c] = fma_s(w[c], t1[c], 3.999999999940941908e-01))
+    HC_V(t2[c] = fma_s(w[c], t2[c], 2.857142874366239149e-01))
+    HC_V(t1[c] = w[c] * t1[c])
+    HC_V(t2[c] = fma_s(w[c], t2[c], 6.666666666666735130e-01))
+    HC_V(t2[c] = z[c] * t2[c])
+    HC_V(a[c] = t2[c] + t1[c])                          // R
+    HC_V(h[c] = 0.5 * f[c] * f[c])                      // hfsq
+    HC_V(dk[c] = (double)ex[c])
+    HC_V(b[c] = g[c] * (h[c] + a[c]) + dk[c] * 1.90821492927058770002e-10)
+    HC_V(b[c] = (h[c] - b[c]) - f[c])
+    HC_V(Lt[c] = dk[c] * 6.93147180369123816490e-01 - b[c])
+    // sig = sqrt_pos(Lt)
+    HC_V(a[c] = __builtin_amdgcn_rsq(Lt[c]))
+    HC_V(g[c] = Lt[c] * a[c])
+    HC_V(h[c] = 0.5 * a[c])
+    HC_V(d[c] = fma(-h[c], g[c], 0.5))
+    HC_V(g[c] = fma(g[c], d[c], g[c]))
+    HC_V(h[c] = fma(h[c], d[c], h[c]))
+    HC_V(d[c] = fma(-g[c], g[c], Lt[c]))
+    HC_V(g[c] = fma(d[c], h[c], g[c]))
+    HC_V(d[c] = fma(-g[c], g[c], Lt[c]))
+    HC_V(g[c] = fma(d[c], h[c], g[c]))
+    HC_V(g[c] = Lt[c] == 0.0 ? 0.0 : g[c])
+    // kb = exp_mid(sig * rnd - Lt / 2 + log m)
+    HC_V(a[c] = fma(g[c], rnd[c], fma(-0.5, Lt[c], logm[c])))
+    HC_V(dk[c] = __builtin_rint(a[c] * 1.4426950408889634))
+    HC_V(a[c] = fma(-dk[c], 6.93147180369123816490e-01, a[c]))
+    HC_V(a[c] = fma(-dk[c], 1.90821492927058770002e-10, a[c]))
+    HC_V(b[c] = fma_s(a[c], 1.0 / 6227020800.0, 1.0 / 479001600.0))
+    HC_V(b[c] = fma_s(b[c], a[c], 1.0 / 39916800.0))
+    HC_V(b[c] = fma_s(b[c], a[c], 1.0 / 3628800.0))
+    HC_V(b[c] = fma_s(b[c], a[c], 1.0 / 362880.0))
+    HC_V(b[c] = fma_s(b[c], a[c], 1.0 / 40320.0))
+    HC_V(b[c] = fma_s(b[c], a[c], 1.0 / 5040.0))
+    HC_V(b[c] = fma_s(b[c], a[c], 1.0 / 720.0))
+    HC_V(b[c] = fma_s(b[c], a[c], 1.0 / 120.0))
+    HC_V(b[c] = fma_s(b[c], a[c], 1.0 / 24.0))
+    HC_V(b[c] = fma_s(b[c], a[c], 1.0 / 6.0))
+    HC_V(b[c] = fma(b[c], a[c], 0.5))
+    HC_V(b[c] = fma(b[c], a[c], 1.0))
+    HC_V(b[c] = fma(b[c], a[c], 1.0))
+    HC_V(b[c] = ldexp(b[c], (int)dk[c]))
+    HC_V(kbo[c] = noisec[c] < 0.0 ? P.sat_soil : b[c])   // cell in no layer: vrettas_fung.py:143
+    HC_V(a[c] = s[c] * kbo[c])                           // <= kb: np.minimum(K, kbkg) is a no-op
+    HC_V(K[c] = sat[c] ? kbo[c] : a[c])
+    // C = m n alpha delta s^3 (alpha |psi|), epsilon when saturated / below epsilon / not finite
+    HC_V(a[c] = s[c] * s[c] * s[c])
+    HC_V(a[c] = P.mn_alpha * delta[c] * a[c] * ap[c])
+    HC_V(C[c] = (int(!sat[c]) & int(a[c] >= P.epsilon) & int(a[c] < INFINITY)) ? a[c] : P.epsilon)
 }
 
 // deepest cell index with pred true, or -1: cells are (lane, c) -> index lane*CPL + c
@@ -339,30 +489,45 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     const double y_top = readlane_d(y[0], 0);
     const double y_nf = shfl_down1(y[0], lane, 0.0);
     double kb_top = 0.0, th_top = 0.0, pf_top = 0.0;
+    {
+        double t_por[CPL], t_logm[CPL], t_invm2[CPL], t_noisec[CPL], kbv[CPL], pfv[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        const int i = lane * CPL + c;
-        const double yn = (c + 1 < CPL) ? y[c + 1 < CPL ? c + 1 : c] : y_nf;
-        const bool vmid = i < D - 1;
-        const bool vtop = (c == CPL - 1) && (lane == WAVE - 1);
-        double psi = 0.5 * (y[c] + yn);
-        double dy = (yn - y[c]) * P.inv_dz;
-        psi = vmid ? psi : (vtop ? y_top : -100.0);
-        dy = vmid ? dy : 0.0;
-        ym[c] = psi;
-        dym[c] = dy;
-        const int slot = c * WAVE + lane;
-        double kb, pf;
-        model_cell<SPECIAL>(P, psi, tab[T_POR * SLOTS + slot], tab[T_INVDELTA * SLOTS + slot], tab[T_LOGM * SLOTS + slot],
-                            tab[T_INVM2 * SLOTS + slot], tab[T_NOISEC * SLOTS + slot], rnd[c], th[c],
-                            Kc[c], Cc[c], kb, pf);
-        fl[c] = Kc[c] * (dy - 1.0);
-        sk[c] = 0.0;
-        if (c == CPL - 1) {
-            kb_top = kb;
-            th_top = th[c];
-            pf_top = pf;
+        for (int c = 0; c < CPL; c++) {
+            const int slot = c * WAVE + lane;
+            t_por[c] = tab[T_POR * SLOTS + slot];
+            t_logm[c] = tab[T_LOGM * SLOTS + slot];
+            t_invm2[c] = tab[T_INVM2 * SLOTS + slot];
+            t_noisec[c] = tab[T_NOISEC * SLOTS + slot];
         }
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int i = lane * CPL + c;
+            const double yn = (c + 1 < CPL) ? y[c + 1 < CPL ? c + 1 : c] : y_nf;
+            const bool vmid = i < D - 1;
+            const bool vtop = (c == CPL - 1) && (lane == WAVE - 1);
+            double psi = 0.5 * (y[c] + yn);
+            double dy = (yn - y[c]) * P.inv_dz;
+            psi = vmid ? psi : (vtop ? y_top : -100.0);
+            dy = vmid ? dy : 0.0;
+            ym[c] = psi;
+            dym[c] = dy;
+        }
+        if (SPECIAL) {
+            model_cells_special<CPL>(P, ym, t_por, t_logm, t_invm2, t_noisec, rnd, th, Kc, Cc, kbv, pfv);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                model_cell<false>(P, ym[c], t_por[c], 0.0, t_logm[c], t_invm2[c], t_noisec[c], rnd[c], th[c], Kc[c],
+                                  Cc[c], kbv[c], pfv[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            fl[c] = Kc[c] * (dym[c] - 1.0);
+            sk[c] = 0.0;
+        }
+        kb_top = kbv[CPL - 1];
+        th_top = th[CPL - 1];
+        pf_top = pfv[CPL - 1];
     }
     const bool normal_mode = !R.spinup;
     // ---- hydraulic lift (night only), richards_pde.py:234-254
@@ -372,8 +537,9 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         for (int c = 0; c < CPL; c++) {
             const int i = lane * CPL + c;
             const bool isr = (i == 0) ? (P.n_root_first > 0) : (i <= P.n_root_int);
+            const double root = tab[T_ROOT * SLOTS + c * WAVE + lane];
             const double t1 = 1.0 - P.ipsi50 * ym[c];
-            const double c_hr = c_sat * (t1 * t1) * tab[T_ROOT * SLOTS + c * WAVE + lane];
+            const double c_hr = c_sat * (t1 * t1) * root;
             const double add = 0.5 * c_hr * (dym[c] * P.dz);
             fl[c] += (isr && i < D - 1) ? add : 0.0;
         }
@@ -385,61 +551,72 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         // inside (wlt, fc] the reference's (theta - fc)/(fc - wlt) is <= 0 and gets clipped to 0.
         if (P.n_root_int > 0) {
             bool isr[CPL];
-            double pre[CPL];
+            double pre[CPL], t_wlt[CPL], t_fc[CPL], t_invd1[CPL], t_root[CPL];
             double s_w = 0.0, s_t = 0.0;
+            // table reads first and unconditional: a read under a per-lane condition becomes a divergent
+            // branch with its own LDS wait
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int slot = c * WAVE + lane;
+                t_wlt[c] = tab[T_WLT * SLOTS + slot];
+                t_fc[c] = tab[T_FC * SLOTS + slot];
+                t_invd1[c] = tab[T_INVD1 * SLOTS + slot];
+                t_root[c] = tab[T_ROOT * SLOTS + slot];
+            }
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
                 const int i = lane * CPL + c;
-                isr[c] = (i >= 1) && (i <= P.n_root_int);
-                s_w += isr[c] ? th[c] - tab[T_WLT * SLOTS + c * WAVE + lane] : 0.0;
+                isr[c] = int(i >= 1) & int(i <= P.n_root_int);
+                const double dw = th[c] - t_wlt[c];
+                s_w += isr[c] ? dw : 0.0;
                 s_t += isr[c] ? th[c] : 0.0;
                 pre[c] = s_t;
             }
-            const double lane_tot = s_t;
-            double tot_theta = s_t;
-            wave_sum2(s_w, tot_theta);
-            double water_k = s_w * P.dz;
+            // one pass: exclusive scan of the lane totals of theta (grand total from its last lane) + sum of s_w
+            double excl = s_t, tot_theta, sum_w = s_w;
+            wave_scan_and_sum(excl, tot_theta, sum_w);
+            double water_k = sum_w * P.dz;
             double x_out[CPL];
+            double tot_x = 0.0;
             if (water_k > 0.0) {
-                const double excl = wave_excl_scan(lane_tot, lane);
                 double total = tot_theta * P.dz;
                 total = total == 0.0 ? 1.0 : total;
-                const double inv_total = 1.0 / total;
+                const double inv_total = fast_rcp(total);
                 bool a2[CPL];
                 bool all_one = true;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
-                    a2[c] = th[c] > tab[T_FC * SLOTS + c * WAVE + lane];
-                    all_one = all_one && (!isr[c] || a2[c]);
+                    a2[c] = th[c] > t_fc[c];
+                    all_one = int(all_one) & (int(!isr[c]) | int(a2[c]));
                 }
                 const double a2v = __all(all_one) ? 0.1 : 1.0;   // "roots drowning" guard, :270-272
-                double s_r = 0.0;
+                double s_r = 0.0, s_rx = 0.0;
                 double rho[CPL];
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
                     const double local = (excl + pre[c]) * P.dz;
-                    const double a1 = fmax(th[c] * tab[T_INVD1 * SLOTS + c * WAVE + lane], local * inv_total);
-                    rho[c] = (isr[c] && a2[c]) ? fabs(a1 * a2v) : 0.0;
+                    const double a1 = fmax(th[c] * t_invd1[c], local * inv_total);
+                    rho[c] = (int(isr[c]) & int(a2[c])) ? fabs(a1 * a2v) : 0.0;
                     s_r += rho[c];
+                    s_rx = fma(rho[c], t_root[c], s_rx);
                 }
-                double tot = wave_sum(s_r) * P.dz;
+                // sum(rho) and sum(rho * root) together: sum(x_out) = sum(rho * root) / tot
+                wave_sum2(s_r, s_rx);
+                double tot = s_r * P.dz;
                 tot = tot == 0.0 ? 1.0 : tot;
-                const double inv_tot = 1.0 / tot;
+                const double inv_tot = fast_rcp(tot);
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
-                    x_out[c] = (rho[c] * inv_tot) * tab[T_ROOT * SLOTS + c * WAVE + lane];
+                    x_out[c] = (rho[c] * inv_tot) * t_root[c];
+                tot_x = (s_rx * inv_tot) * P.dz;
             } else {
                 water_k = 0.0;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) x_out[c] = 0.0;
             }
-            double s_x = 0.0;
-#pragma unroll
-            for (int c = 0; c < CPL; c++) s_x += isr[c] ? x_out[c] : 0.0;
-            double tot_x = wave_sum(s_x) * P.dz;
             if (tot_x > 1.0) {
-                const double inv_tx = 1.0 / tot_x;
-                s_x = 0.0;
+                const double inv_tx = fast_rcp(tot_x);
+                double s_x = 0.0;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
                     x_out[c] = x_out[c] * inv_tx;
@@ -448,7 +625,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                 tot_x = wave_sum(s_x) * P.dz;
             }
             if (tot_x > 0.0) {
-                const double tr_pot = fmin(R.atm, water_k) / tot_x;
+                const double tr_pot = fast_div(fmin(R.atm, water_k), tot_x);
 #pragma unroll
                 for (int c = 0; c < CPL; c++) sk[c] = isr[c] ? -(tr_pot * x_out[c]) : sk[c];
                 if (R.diag) {   // richards_pde.py:380-381: sum(uptake) * dz of the interior call
@@ -460,28 +637,26 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             }
         }
         // (b) first-midpoint call: one cell normalised on its own
-        if (P.n_root_first > 0 && lane == 0) {
+        if (P.n_root_first > 0) {
+            // evaluated by every lane on its own slot-0 cell (no divergent branch); only lane 0's result is kept
             const double t0 = th[0], w0 = tab[T_WLT * SLOTS + lane], f0 = tab[T_FC * SLOTS + lane];
-            double water_k = (t0 - w0) * P.dz;
-            double x0 = 0.0;
-            if (water_k > 0.0) {
-                const double local = t0 * P.dz;
-                const double total = local == 0.0 ? 1.0 : local;
-                const double a1 = fmax(t0 * tab[T_INVD1 * SLOTS + lane], local / total);
-                const double v = t0 > f0 ? 0.1 : 0.0;        // single cell: all-ones guard always applies
-                double rho = fabs(a1 * v);
-                double tot = rho * P.dz;
-                tot = tot == 0.0 ? 1.0 : tot;
-                x0 = (rho / tot) * tab[T_ROOT * SLOTS + lane];
-            } else {
-                water_k = 0.0;
-            }
+            const double water_k = fmax((t0 - w0) * P.dz, 0.0);
+            const double local = t0 * P.dz;
+            const double ratio = local == 0.0 ? 0.0 : 1.0;              // local / (local or 1): exactly 0 or 1
+            const double a1 = fmax(t0 * tab[T_INVD1 * SLOTS + lane], ratio);
+            // single cell: the all-ones guard always applies, alpha_02 * 0.1 (tree_roots.py:270-272)
+            const double rho = (water_k > 0.0 && t0 > f0) ? fabs(a1 * 0.1) : 0.0;
+            double tot = rho * P.dz;
+            tot = tot == 0.0 ? 1.0 : tot;
+            double x0 = fast_div(rho, tot) * tab[T_ROOT * SLOTS + lane];
             double tot_x = x0 * P.dz;
-            if (tot_x > 1.0) {
-                x0 = x0 / tot_x;
-                tot_x = x0 * P.dz;
-            }
-            if (tot_x > 0.0) sk[0] = -((fmin(R.atm, water_k) / tot_x) * x0);
+            const bool big = tot_x > 1.0;
+            const double x0n = fast_div(x0, big ? tot_x : 1.0);
+            x0 = big ? x0n : x0;
+            tot_x = big ? x0 * P.dz : tot_x;
+            const bool on = tot_x > 0.0;
+            const double s0 = -(fast_div(fmin(R.atm, water_k), on ? tot_x : 1.0) * x0);
+            sk[0] = (lane == 0 && on) ? s0 : sk[0];
         }
     }
     // ---- lateral flow, monitoring mode, richards_pde.py:352-376 (interior slice only; the

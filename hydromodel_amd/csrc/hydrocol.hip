@@ -199,6 +199,14 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
         idx = (i < D - 1) ? idx : 0;
         rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * nz[(idx % CPL) * WAVE + idx / CPL];
     }
+#ifdef HC_PROFILE
+    // diagnostic build: repeat the evaluation (loop-carried through y) to time the RHS alone
+    for (long long rep = 1; rep < A.n_rows; rep++) {
+        rhs_eval<CPL, SPECIAL>(P, R, tab, lane, y, rnd, f, nullptr, dtr, dlf);
+#pragma unroll
+        for (int c = 0; c < CPL; c++) y[c] = fma(f[c], 1e-300, y[c]);
+    }
+#endif
     rhs_eval<CPL, SPECIAL>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr, dtr, dlf);
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
@@ -274,7 +282,11 @@ template <int CPL, bool SPECIAL, int WPB>
 int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
 {
     auto kern = rhs_kernel<CPL, SPECIAL, WPB>;
+#ifdef HC_PROFILE
+    const size_t lds = step_lds_bytes(CPL, WPB);   // same occupancy as the step kernel
+#else
     const size_t lds = rhs_lds_bytes(CPL, WPB);
+#endif
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     const unsigned grid = (unsigned)((A.n_members + WPB - 1) / WPB);
@@ -771,6 +783,9 @@ int hc_rhs(hc_handle *h, int64_t row, int32_t spinup, double *dydt, double *aux)
     A.spinup = spinup;
     rc = push_io(h);
     if (rc) return rc;
+#ifdef HC_PROFILE
+    if (const char *e = getenv("HYDROCOL_RHS_REPEAT")) A.n_rows = atoll(e);
+#endif
     rc = launch_rhs(h, A, row, h->scratch_d.p, aux ? h->scratch_d.p + n : nullptr);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
