@@ -102,7 +102,7 @@ def main():
     local_rank = dev_index
 
     from hydromodel_amd.digest import ColumnTables, ForcingDigest
-    from hydromodel_amd.ensemble import EnsembleSimulation, allreduce_moments, spinup_on_gpu
+    from hydromodel_amd.ensemble import PHILOX_DRAW_SPINUP, EnsembleSimulation, allreduce_moments, spinup_on_gpu
     from hydromodel_amd.stepper import EnsembleStepper
     from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
 
@@ -117,7 +117,7 @@ def main():
     # shared initial condition: every rank computes the same member-0 spin-up (deterministic)
     probe = EnsembleStepper(cols, forcing, 1, device=local_rank)
     probe.set_noise_philox(args.seed, 0)
-    n_rnd0 = probe.philox_normals(0, 0)
+    n_rnd0 = probe.philox_normals(0, PHILOX_DRAW_SPINUP)
     probe.close()
     psi0, spin_iters, _ = spinup_on_gpu(cols, forcing, n_rnd0, device=local_rank)
 

@@ -38,6 +38,12 @@ class StepArgs(C.Structure):
                 ("launches", C.c_int64)]
 
 
+class SpinupArgs(C.Structure):
+    """hc_spinup_args"""
+    _fields_ = [("forcing_row", C.c_int64), ("max_iterations", C.c_int32), ("zwtd_cm", C.c_double),
+                ("z0_cm", C.c_double), ("iterations_out", _ip), ("kernel_ms", C.c_double)]
+
+
 EXPORTS = {
     "hc_create": ([C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     "hc_destroy": ([C.c_void_p], C.c_int),
@@ -53,6 +59,7 @@ EXPORTS = {
     "hc_set_noise_philox": ([C.c_void_p, C.c_uint64, C.c_int64], C.c_int),
     "hc_philox_normals": ([C.c_void_p, C.c_int64, C.c_int64, _dp], C.c_int),
     "hc_step_rows": ([C.c_void_p, C.POINTER(StepArgs)], C.c_int),
+    "hc_spinup": ([C.c_void_p, C.POINTER(SpinupArgs)], C.c_int),
     "hc_synchronize": ([C.c_void_p], C.c_int),
     "hc_get_counters": ([C.c_void_p, C.POINTER(C.c_uint64)], C.c_int),
     "hc_get_moments": ([C.c_void_p, _lp], C.c_int),

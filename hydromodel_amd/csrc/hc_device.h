@@ -341,15 +341,20 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
 // independent dependency chains are interleaved in program order.  With one wave per SIMD nothing else hides
 // the latency of a dependent fp64 instruction, and the compiler does not interleave the chains by itself.
 // Same operations in the same order per cell as model_cell<true>.
+#ifndef HC_MODEL_BATCH
+#define HC_MODEL_BATCH 5
+#endif
 #define HC_V(...)                         \
     _Pragma("unroll") for (int c = 0; c < N; c++) { __VA_ARGS__; }
-template <int N>
-__device__ __forceinline__ void model_cells_special(const ColumnDev &P, const double (&psi)[N], const double (&por)[N],
-                                                    const double (&logm)[N], const double (&invm2)[N],
-                                                    const double (&noisec)[N], const double (&rnd)[N],
-                                                    double (&theta)[N], double (&K)[N], double (&C)[N],
-                                                    double (&kbo)[N], double (&pfac)[N])
+template <int N, int SLOTS>
+__device__ __forceinline__ void model_cells_special(const ColumnDev &P, const double *tab, int slot0,
+                                                    const double *psi, const double *rnd, double *theta, double *K,
+                                                    double *C, double *kbo, double *pfac)
 {
+    // tab + slot0 addresses cell 0 of the batch; cell c is WAVE slots further.  Each table is read where it
+    // is first needed, not at the top: four more live vectors would push caller state out of the VGPR file.
+    double por[N], invm2[N], logm[N], noisec[N];
+    HC_V(por[c] = tab[T_POR * SLOTS + slot0 + c * WAVE])
     double delta[N], ap[N], a[N], b[N], d[N], e[N], g[N], h[N], s[N], Lt[N], f[N], z[N], w[N], t1[N], t2[N], dk[N];
     bool sat[N], lo[N];
     int ex[N];
@@ -378,6 +383,7 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     HC_V(s[c] = fma(e[c], b[c], d[c]))
     HC_V(s[c] = fmin(fmax(s[c], 0.0), 1.0))
     // t = 1 + sigma (1 - s) / m^2;  Lt = log_pos(t)
+    HC_V(invm2[c] = tab[T_INVM2 * SLOTS + slot0 + c * WAVE])
     HC_V(a[c] = P.sigma * (1.0 - s[c]))
     HC_V(a[c] = fma(a[c], invm2[c], 1.0))
     HC_V(b[c] = __builtin_amdgcn_frexp_mant(a[c]))
@@ -411,6 +417,8 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     HC_V(b[c] = (h[c] - b[c]) - f[c])
     HC_V(Lt[c] = dk[c] * 6.93147180369123816490e-01 - b[c])
     // sig = sqrt_pos(Lt)
+    HC_V(logm[c] = tab[T_LOGM * SLOTS + slot0 + c * WAVE])
+    HC_V(noisec[c] = tab[T_NOISEC * SLOTS + slot0 + c * WAVE])
     HC_V(a[c] = __builtin_amdgcn_rsq(Lt[c]))
     HC_V(g[c] = Lt[c] * a[c])
     HC_V(h[c] = 0.5 * a[c])
@@ -490,15 +498,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     const double y_nf = shfl_down1(y[0], lane, 0.0);
     double kb_top = 0.0, th_top = 0.0, pf_top = 0.0;
     {
-        double t_por[CPL], t_logm[CPL], t_invm2[CPL], t_noisec[CPL], kbv[CPL], pfv[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const int slot = c * WAVE + lane;
-            t_por[c] = tab[T_POR * SLOTS + slot];
-            t_logm[c] = tab[T_LOGM * SLOTS + slot];
-            t_invm2[c] = tab[T_INVM2 * SLOTS + slot];
-            t_noisec[c] = tab[T_NOISEC * SLOTS + slot];
-        }
+        double kbv[CPL], pfv[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
             const int i = lane * CPL + c;
@@ -513,12 +513,26 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             dym[c] = dy;
         }
         if (SPECIAL) {
-            model_cells_special<CPL>(P, ym, t_por, t_logm, t_invm2, t_noisec, rnd, th, Kc, Cc, kbv, pfv);
+            // batches of HC_MODEL_BATCH cells: enough independent chains to hide the fp64 latency, few
+            // enough to keep the working set in VGPRs
+            constexpr int B = HC_MODEL_BATCH < CPL ? HC_MODEL_BATCH : CPL;
+            constexpr int NB = CPL / B, REM = CPL - NB * B;
+#pragma unroll
+            for (int q = 0; q < NB; q++)
+                model_cells_special<B, SLOTS>(P, tab, q * B * WAVE + lane, ym + q * B, rnd + q * B, th + q * B,
+                                              Kc + q * B, Cc + q * B, kbv + q * B, pfv + q * B);
+            if (REM > 0)
+                model_cells_special<(REM > 0 ? REM : 1), SLOTS>(P, tab, NB * B * WAVE + lane, ym + NB * B, rnd + NB * B,
+                                                                th + NB * B, Kc + NB * B, Cc + NB * B, kbv + NB * B,
+                                                                pfv + NB * B);
         } else {
 #pragma unroll
-            for (int c = 0; c < CPL; c++)
-                model_cell<false>(P, ym[c], t_por[c], 0.0, t_logm[c], t_invm2[c], t_noisec[c], rnd[c], th[c], Kc[c],
+            for (int c = 0; c < CPL; c++) {
+                const int slot = c * WAVE + lane;
+                model_cell<false>(P, ym[c], tab[T_POR * SLOTS + slot], 0.0, tab[T_LOGM * SLOTS + slot],
+                                  tab[T_INVM2 * SLOTS + slot], tab[T_NOISEC * SLOTS + slot], rnd[c], th[c], Kc[c],
                                   Cc[c], kbv[c], pfv[c]);
+            }
         }
 #pragma unroll
         for (int c = 0; c < CPL; c++) {

@@ -59,7 +59,10 @@ struct IoArgs {
     double *diag;             // [n_rows][N][2] transpiration, lateral flow of the row's last RHS evaluation, or null
     unsigned long long *counters;   // [0] FD-Jacobian retry passes, [1] failed attempts, [2] loop-guard trips
     unsigned long long *queue;      // member ticket of the persistent grid, zeroed before every launch
+    int *spin_iters;          // [N] spin-up with the stop rule: solves used (negative: cap reached), or null
 };
+
+constexpr unsigned PHILOX_DRAW_SPINUP = 0xFFFFFFFFu;
 
 struct StepArgs {
     const ColumnDev *P;       // device memory
@@ -70,6 +73,9 @@ struct StepArgs {
     int n_rows, spinup, D, n_groups, host_noise;
     double psi_sat;
     double jac_reject;        // NUM_JAC_DIFF_REJECT = EPS**0.875 (debug override: HYDROCOL_DEBUG_JAC_REJECT)
+    // spin-up with the per-member stop rule of simulation.py:468 evaluated in the kernel (hc_spinup)
+    int spin_stop;
+    double spin_zwtd, spin_z0, spin_dz;
 };
 
 // Uniform struct load from device memory through the constant address space (s_load_dwordxN).  The empty
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
             R.diag = io.diag != nullptr;
             refresh = !A.spinup && io.refresh[row];
         }
-        double diag_tr = 0.0, diag_lf = 0.0;
+        double diag_tr = 0.0, diag_lf = 0.0, spin_mse = INFINITY;
         const double t0 = A.spinup ? 0.0 : (double)(row - 1);
         const double tf = t0 + 1.0;
         int st_nfev = 0, st_njev = 0, st_nlu = 0, st_nsteps = 0, attempts = 0;
@@ -440,7 +446,10 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
             // ---- noise vector of this row -> V_NZ (simulation.py:592,599-602)
             {
                 const IoArgs io = load_const(A.io);
-                const unsigned draw = (refresh && !A.host_noise) ? (unsigned)io.draw_idx[row] : 0u;
+                // Philox draws mirror the reference's order (simulation.py:426,561,601): the spin-up vector has
+                // its own index, 0 is the base vector, refresh row k uses draw k >= 1
+                const unsigned draw = A.spinup ? PHILOX_DRAW_SPINUP
+                                               : ((refresh && !A.host_noise) ? (unsigned)io.draw_idx[row] : 0u);
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
                     const int i = lane * CPL + c;
@@ -982,6 +991,15 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 __builtin_amdgcn_wave_barrier();
                 if (attempts >= 5) break;
             }
+            if (A.spin_stop) {   // mean((y_j - y_{j-1})^2), simulation.py:457
+                double sq = 0.0;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    const double dlt = V[V_Y * SLOTS + c * WAVE + lane] - yrow0[c];
+                    sq = fma(dlt, dlt, sq);
+                }
+                spin_mse = wave_sum(sq) / (double)D;
+            }
             if (failed) {
                 const IoArgs io = load_const(A.io);
                 if (lane == 0) atomicAdd(&io.counters[1], (unsigned long long)failed);
@@ -1005,7 +1023,16 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         int w = istar < 0 ? 0 : istar + 1;
         w = w < D - 1 ? w : D - 1;
         if (skip) w = 0;
-        {
+        if (A.spin_stop) {
+            // Simulation.initial_conditions stop rule (simulation.py:452-468): water table within 2 dz of the
+            // first observation and a mean squared change of the state <= 0.01; no per-row outputs
+            const double abs_error = fabs(A.spin_zwtd - (A.spin_z0 + (double)w * A.spin_dz));
+            const bool stop = (abs_error <= 2.0 * A.spin_dz) && (spin_mse <= 0.01);
+            if (stop || r == A.n_rows - 1) {
+                if (lane == 0) load_const(A.io).spin_iters[member] = stop ? r + 1 : -(r + 1);
+                break;
+            }
+        } else {
             const IoArgs io = load_const(A.io);
             if (lane == 0) {
                 io.wtd_u16[(size_t)r * A.n_members + member] = (unsigned short)w;

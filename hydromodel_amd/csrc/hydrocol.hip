@@ -75,6 +75,7 @@ struct hc_handle {
     int cpl = 0, wpb = 0, slots = 0;
     bool special = false;
     DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
+    DevBuf<int> spin_iters;
     DevBuf<int> gtab, wtd_obs, draw_idx, stats, scratch_i;
     DevBuf<unsigned char> daylight, refresh;
     DevBuf<unsigned short> wtd_u16;
@@ -413,6 +414,7 @@ int hc_destroy(hc_handle *h)
     h->tab.release(); h->node_tabs.release(); h->precip.release(); h->atm.release(); h->psi.release();
     h->base.release(); h->nscale.release(); h->fresh.release(); h->psi_rows.release(); h->scratch_d.release();
     h->diag.release();
+    h->spin_iters.release();
     h->gtab.release(); h->wtd_obs.release(); h->draw_idx.release(); h->stats.release(); h->scratch_i.release();
     h->Pdev.release(); h->iodev.release();
     h->daylight.release(); h->refresh.release(); h->wtd_u16.release(); h->moments.release(); h->counters.release();
@@ -709,6 +711,44 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
         fresh_consumed += n_fresh;
         done += chunk;
     }
+    unsigned long long cnt[4];
+    HIP_TRY(hipMemcpy(cnt, h->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+    if (cnt[2] != 0)
+        return fail(HC_ERR_DEVICE, "%llu BDF attempts hit the kernel's iteration guard (non-terminating step control)",
+                    cnt[2]);
+    return HC_OK;
+}
+
+int hc_spinup(hc_handle *h, hc_spinup_args *a)
+{
+    if (!h || !a || !a->iterations_out) return fail(HC_ERR_ARG, "hc_spinup: NULL argument");
+    StepArgs A;
+    int rc = fill_args(h, A);
+    if (rc) return rc;
+    if (a->forcing_row < 0 || a->forcing_row >= h->n_rows) return fail(HC_ERR_ARG, "spin-up forcing row out of range");
+    if (a->max_iterations < 1 || a->max_iterations > 1000000) return fail(HC_ERR_ARG, "max_iterations out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t N = h->n_members;
+    if (h->spin_iters.ensure((size_t)N)) return HC_ERR_DEVICE;
+    h->io_host.row_begin = a->forcing_row;
+    h->io_host.spin_iters = h->spin_iters.p;
+    A.n_rows = a->max_iterations;
+    A.spinup = 1;
+    A.spin_stop = 1;
+    A.spin_zwtd = a->zwtd_cm;
+    A.spin_z0 = a->z0_cm;
+    A.spin_dz = h->p.dz;
+    rc = push_io(h);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    rc = launch_step(h, A);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipMemcpyAsync(a->iterations_out, h->spin_iters.p, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    a->kernel_ms = ms;
     unsigned long long cnt[4];
     HIP_TRY(hipMemcpy(cnt, h->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
     if (cnt[2] != 0)

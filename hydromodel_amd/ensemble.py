@@ -72,20 +72,69 @@ def spinup_on_gpu(cols, forcing, n_rnd, device=0, burn_in=1500, flags=None, verb
     return y0, j + 1, early_stop
 
 
-class EnsembleSimulation:
-    """N members of one parameter point on one device; Philox noise generated in-kernel."""
+PHILOX_DRAW_SPINUP = 0xFFFFFFFF          # include/hydrocol.h: HC_PHILOX_DRAW_SPINUP
 
-    def __init__(self, cols, forcing, n_members, seed=0, device=0, member_offset=0, psi0=None, flags=None):
+
+def spinup_members_on_gpu(stepper, cols, forcing, burn_in=1500):
+    """``Simulation.initial_conditions`` for EVERY member of `stepper` at once: each member starts
+    from the hydrostatic-like profile of simulation.py:409-414, keeps the noise source already installed in
+    `stepper` (host vectors or its Philox stream, draw 0), and stops by its own rule (simulation.py:468), all
+    inside one kernel launch.  Returns (psi0[N][D], iterations[N]); iterations < 0 marks members that ran into
+    `burn_in` (the reference prints "finished at maximum number of iterations" and carries on)."""
+    y0, _ = pressure_head(cols, cols.por_raw)
+    stepper.set_state(y0)
+    iters, _ = stepper.spinup(forcing.zwtd_cm[0], cols.z[0], forcing_row=0, max_iterations=burn_in)
+    return stepper.get_state(), iters
+
+
+def member_generators(seed, n_members, member_offset=0):
+    """NumPy streams of a parity-style ensemble: global member 0 consumes exactly the
+    reference's ``default_rng(SeedSequence(seed))`` (simulation.py:66-70); member k >= 1 uses
+    ``SeedSequence(seed, spawn_key=(k,))``."""
+    from numpy.random import SeedSequence, default_rng
+    gens = []
+    for k in range(member_offset, member_offset + n_members):
+        gens.append(default_rng(SeedSequence(seed) if k == 0 else SeedSequence(seed, spawn_key=(k,))))
+    return gens
+
+
+class EnsembleSimulation:
+    """N members of one parameter point on one device.
+
+    noise="philox" (default): counter-based normals generated in the kernel, keyed by the global member id.
+    noise="numpy": host NumPy streams (`member_generators`), drawn in the reference's order -- #0 spin-up,
+    #1 base vector, then one vector per refresh row (simulation.py:426,561,601) -- and uploaded per launch.
+    spinup="shared" (default): one spin-up (global member 0's first draw) broadcast to all members;
+    spinup="member": every member spins up with its own first draw (`spinup_members_on_gpu`).
+    """
+
+    def __init__(self, cols, forcing, n_members, seed=0, device=0, member_offset=0, psi0=None, flags=None,
+                 noise="philox", spinup="shared"):
+        if noise not in ("philox", "numpy") or spinup not in ("shared", "member"):
+            raise ValueError(f" {self.__class__.__name__}: unknown noise / spinup mode ({noise}, {spinup}).")
         self.cols, self.forcing = cols, forcing
         self.n_members = int(n_members)
         self.member_offset = int(member_offset)
         self.seed = int(seed)
         self.device = device
+        self.noise = noise
+        self.spinup_iters = None
+        if noise == "numpy":
+            self._init_numpy(psi0, flags, spinup)
+            return
+        if psi0 is None and spinup == "member":
+            self.stepper = EnsembleStepper(cols, forcing, self.n_members, device=device, flags=flags)
+            self.stepper.set_noise_philox(self.seed, self.member_offset)
+            self.psi0, self.spinup_iters = spinup_members_on_gpu(self.stepper, cols, forcing)
+            # the x0.8 damping a spin-up retry applied belongs to the spin-up vector, not to the run's base vector
+            self.stepper.set_noise_philox(self.seed, self.member_offset)
+            self.next_row, self.kernel_ms, self.launches = 1, 0.0, 0
+            return
         if psi0 is None:
             # shared initial condition: spin-up with the noise vector of global member 0, draw 0
             probe = EnsembleStepper(cols, forcing, 1, device=device, flags=flags)
             probe.set_noise_philox(self.seed, 0)
-            n_rnd = probe.philox_normals(0, 0)
+            n_rnd = probe.philox_normals(0, PHILOX_DRAW_SPINUP)     # global member 0's spin-up vector
             probe.close()
             psi0, self.spinup_iters, _ = spinup_on_gpu(cols, forcing, n_rnd, device=device, flags=flags)
         self.psi0 = np.asarray(psi0, dtype=float)
@@ -96,8 +145,35 @@ class EnsembleSimulation:
         self.kernel_ms = 0.0
         self.launches = 0
 
+    def _init_numpy(self, psi0, flags, spinup):
+        cols, forcing, N, D = self.cols, self.forcing, self.n_members, self.cols.dim_d
+        self.gens = member_generators(self.seed, N, self.member_offset)
+        self.stepper = EnsembleStepper(cols, forcing, N, device=self.device, flags=flags)
+        if psi0 is None:
+            first = np.stack([g.standard_normal(D) for g in self.gens])           # draw #0 (simulation.py:426)
+            if spinup == "member":
+                self.stepper.set_noise_host(first)
+                psi0, self.spinup_iters = spinup_members_on_gpu(self.stepper, cols, forcing)
+            else:
+                if self.member_offset == 0:
+                    lead = first[0]
+                else:       # every shard spins up with global member 0's first draw
+                    lead = member_generators(self.seed, 1, 0)[0].standard_normal(D)
+                psi0, self.spinup_iters, _ = spinup_on_gpu(cols, forcing, lead, device=self.device, flags=flags)
+        self.psi0 = np.asarray(psi0, dtype=float)
+        self.stepper.set_state(self.psi0)
+        self.stepper.set_noise_host(np.stack([g.standard_normal(D) for g in self.gens]))   # draw #1 (:561)
+        self.next_row, self.kernel_ms, self.launches = 1, 0.0, 0
+
     def advance(self, n_rows, **kw):
         """Solve the next ``n_rows`` forcing rows for every member."""
+        if self.noise == "numpy":
+            n_fresh = int(self.forcing.refresh[self.next_row:self.next_row + n_rows].sum())
+            fresh = np.empty((n_fresh, self.n_members, self.cols.dim_d))
+            for q in range(n_fresh):                 # row order, one vector per member per refresh row (:601)
+                for k, g in enumerate(self.gens):
+                    fresh[q, k] = g.standard_normal(self.cols.dim_d)
+            kw["fresh_noise"] = fresh
         out = self.stepper.step_rows(self.next_row, n_rows, **kw)
         self.next_row += n_rows
         self.kernel_ms += out["kernel_ms"]

@@ -158,6 +158,18 @@ class EnsembleStepper:
         L.check(self.lib.hc_reset_moments(self.h))
 
     # -- hooks ----------------------------------------------------------------------
+    def spinup(self, zwtd_cm, z0_cm, forcing_row=0, max_iterations=1500):
+        """Per-member ``Simulation.initial_conditions`` (simulation.py:389-493) in one launch: every member
+        iterates from its current state with its own noise vector until its own stop rule holds.
+        Returns (iterations[N] -- negative where the cap was reached, kernel_ms)."""
+        iters = np.zeros(self.N, dtype=np.int32)
+        a = L.SpinupArgs()
+        a.forcing_row, a.max_iterations = int(forcing_row), int(max_iterations)
+        a.zwtd_cm, a.z0_cm = float(zwtd_cm), float(z0_cm)
+        a.iterations_out = L.iptr(iters)
+        L.check(self.lib.hc_spinup(self.h, C.byref(a)))
+        return iters, a.kernel_ms
+
     def rhs(self, row, spinup=False, want_aux=False):
         out = np.empty((self.N, self.D))
         M = self.D - 1

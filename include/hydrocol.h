@@ -16,6 +16,7 @@
  *   hc_step_rows       <- the row loop body: RichardsPDE.solve(t_span, y0, args_i)
  *                         (src/richards_pde.py:478-537 -> scipy solve_ivp BDF) followed by
  *                         find_wtd(y_i >= psi_sat) (src/simulation.py:609-612)
+ *   hc_spinup          <- Simulation.initial_conditions (src/simulation.py:389-493), per member
  *   hc_rhs             <- RichardsPDE.__call__(t, y, args)   (src/richards_pde.py:82-160)
  *   hc_model_nodes     <- h_model(y_i, z, args_i) diagnostics call (src/simulation.py:623;
  *                         src/models/vrettas_fung.py:51 / vanGenuchten.py:23)
@@ -95,6 +96,9 @@ int hc_get_noise_base(hc_handle *h, double *base, int64_t first_member, int64_t 
  * stream = (seed, member_offset + member, draw index, depth).  The retry damping is kept as a
  * per-member scale factor. */
 int hc_set_noise_philox(hc_handle *h, uint64_t seed, int64_t member_offset);
+/* draw indices: 0 = base vector, k >= 1 = k-th refresh row, HC_PHILOX_DRAW_SPINUP = the vector spin-up solves use
+ * (the reference draws spin-up, base, refresh... in that order: src/simulation.py:426,561,601) */
+#define HC_PHILOX_DRAW_SPINUP 0xFFFFFFFFll
 /* What the Philox source yields for (member, draw): out[D] (test hook). */
 int hc_philox_normals(hc_handle *h, int64_t member, int64_t draw, double *out);
 
@@ -116,6 +120,21 @@ typedef struct {
 } hc_step_args;
 
 int hc_step_rows(hc_handle *h, hc_step_args *a);
+
+/* Simulation.initial_conditions (src/simulation.py:389-493) for every member in ONE launch: each member
+ * repeats the solve of `forcing_row` over t in (0, 1) with SPINUP semantics and its own fixed noise vector,
+ * starting from the state set by hc_set_state, until its own stop rule holds (src/simulation.py:468:
+ * |zwtd_cm - z[wtd_est]| <= 2 dz and mean((y_j - y_{j-1})^2) <= 0.01) or max_iterations solves are done.
+ * The members' states are left in place (hc_get_state). */
+typedef struct {
+    int64_t forcing_row;      /* 0 in the reference                                                */
+    int32_t max_iterations;   /* burn_in = 1500 in the reference (src/simulation.py:420)           */
+    double zwtd_cm;           /* first water-table observation, cm                                 */
+    double z0_cm;             /* depth of node 0: z[i] = z0_cm + i * dz                            */
+    int32_t *iterations_out;  /* [n_members] solves used; negative = stopped by max_iterations     */
+    double kernel_ms;         /* out */
+} hc_spinup_args;
+int hc_spinup(hc_handle *h, hc_spinup_args *a);
 int hc_synchronize(hc_handle *h);
 /* event counters since hc_create: [0] FD-Jacobian passes that took num_jac's "difference too small ->
  * retry with a 10x step" branch, [1] failed BDF attempts (each scales the noise by 0.8), [2] kernel

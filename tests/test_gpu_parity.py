@@ -642,3 +642,84 @@ def test_diagnostics_off_and_on_give_the_same_states(gpu):
     assert d.shape == (48, 5, 2) and (d >= 0).all() and d[:, :, 0].max() > 0
     night = ~forcing.daylight[1:49].astype(bool)
     assert (d[night, :, 0] == 0).all()      # ET acts in daylight only (richards_pde.py:258)
+
+
+# ------------------------------------------------------------------------------- §8(f1) per-member spin-up
+def test_per_member_spinup_in_one_launch(gpu):
+    """hc_spinup: every member iterates with its own noise vector until its own stop rule (simulation.py:468)
+    holds, all inside one launch.  Member 0 carries the reference's spin-up draw -> the reference's IC."""
+    from hydromodel_amd.ensemble import pressure_head, spinup_members_on_gpu, spinup_on_gpu
+    _, cols, forcing = digest(200)
+    g = golden("g1_tables_200.npz")
+    N, D = 6, cols.dim_d
+    noise = np.random.default_rng(5).standard_normal((N, D))
+    noise[0] = np.random.default_rng(np.random.SeedSequence(911)).standard_normal(D)
+    st = gpu.EnsembleStepper(cols, forcing, N)
+    st.set_noise_host(noise)
+    psi0, iters = spinup_members_on_gpu(st, cols, forcing)
+    assert psi0.shape == (N, D) and (iters > 0).all(), iters
+    assert np.max(np.abs(psi0[0] - g["initial_cond"])) < 0.02          # ~115 chained solves, chaotic last bits
+    assert len(set(iters.tolist())) > 1 or not np.allclose(psi0[1], psi0[2])    # members really differ
+    # same answer as the host-driven loop (one launch per solve, stop rule in NumPy) for two members
+    for k in (0, 3):
+        ic, it, early = spinup_on_gpu(cols, forcing, noise[k])
+        assert early and abs(it - iters[k]) <= 2, (k, it, iters[k])
+        assert np.max(np.abs(ic - psi0[k])) < 0.05
+    # and as the CPU oracle's spin-up
+    o = _oracle(cols, forcing)
+    y0, _ = pressure_head(cols, cols.por_raw)
+    for k in (1, 4):
+        ic, it = o.spinup(_row(forcing, 0), forcing.zwtd_cm[0], y0, noise[k])
+        assert abs(it - iters[k]) <= 2, (k, it, iters[k])
+        assert np.max(np.abs(ic - psi0[k])) < 0.05
+    # the cap: members that cannot finish in 3 solves report -3 and keep their 3-solve state
+    st.set_state(y0)
+    st.set_noise_host(noise)
+    it3, _ = st.spinup(forcing.zwtd_cm[0], cols.z[0], max_iterations=3)
+    assert (it3 == -3).all()
+    st.close()
+
+
+def test_numpy_seeded_ensemble_member0_is_the_single_column_run(gpu):
+    """Config C2 seeding: member 0 consumes default_rng(SeedSequence(seed)) exactly like the
+    reference's single-column run, member k the stream spawn_key=(k,); every member equals the oracle fed the
+    same vectors."""
+    from hydromodel_amd.ensemble import EnsembleSimulation, member_generators
+    _, cols, forcing = digest(1)
+    g = golden("g5_traj_1.npz")
+    N, D, rows = 5, cols.dim_d, 96
+    sim = EnsembleSimulation(cols, forcing, N, seed=911, noise="numpy")      # shared spin-up with member 0's draw #0
+    assert np.max(np.abs(sim.psi0 - g["initial_cond"])) < 0.02
+    out = sim.advance(rows, want_wtd=True, want_psi=True)
+    # member 0 = the reference's stream (spin-up, base, refresh...): the reference's own first two days
+    ref_idx = np.rint(g["wtd_est_cm"][1:1 + rows] / cols.dz).astype(int)
+    assert (out["wtd"][:, 0] == ref_idx).mean() > 0.97
+    assert np.max(np.abs(out["psi"][0, 0] - g["rec_y1"][0])) < 0.02
+    o = _oracle(cols, forcing)
+    n_fresh = int(forcing.refresh[1:1 + rows].sum())
+    for k, gen in enumerate(member_generators(911, N)):
+        gen.standard_normal(D)                              # draw #0: spin-up (simulation.py:426)
+        base = gen.standard_normal(D)                       # draw #1: base vector (:561)
+        fresh = np.stack([gen.standard_normal(D) for _ in range(n_fresh)])
+        r = o.run(forcing, sim.psi0, base, fresh, 1, 1 + rows, want_psi=True)
+        assert (out["wtd"][:, k] == r["wtd_est"][1:1 + rows]).mean() > 0.97, k
+        assert np.max(np.abs(out["psi"][0, k] - r["psi_rows"][1])) < 1e-8
+    assert not np.array_equal(out["wtd"][:, 1], out["wtd"][:, 2]) or not np.array_equal(out["psi"][-1, 1], out["psi"][-1, 2])
+    sim.close()
+
+
+def test_philox_spinup_modes(gpu):
+    from hydromodel_amd.ensemble import PHILOX_DRAW_SPINUP, EnsembleSimulation
+    _, cols, forcing = digest(200)
+    shared = EnsembleSimulation(cols, forcing, 4, seed=3)
+    per = EnsembleSimulation(cols, forcing, 4, seed=3, spinup="member")
+    assert per.psi0.shape == (4, cols.dim_d) and (per.spinup_iters > 0).all()
+    # global member 0 spins up with the same vector in both modes
+    assert np.max(np.abs(per.psi0[0] - shared.psi0)) < 0.05
+    assert not np.allclose(per.psi0[1], per.psi0[2])
+    # the spin-up vector is its own Philox draw, distinct from the base vector
+    v_spin = per.stepper.philox_normals(0, PHILOX_DRAW_SPINUP)
+    assert not np.array_equal(v_spin, per.stepper.philox_normals(0, 0))
+    a = per.advance(48, want_wtd=True)
+    assert a["wtd"].shape == (48, 4)
+    shared.close(); per.close()
