@@ -7,8 +7,10 @@ exit codes (any error -> message + exit status 1, :138-142).  Additions (the ref
 unknown keys, only membership of the 12 is checked):
 
 * ``--seed`` / JSON ``"Seed"``: seeds ``Simulation(name, seed)``; the reference's CLI cannot be seeded.
-* JSON ``"Ensemble": {"Members": N, "Seed": s, "Days": d}``: run N stochastic members with in-kernel
-  Philox noise and write the per-row water-table mean / sigma to ``<Output_Name>_ensemble.h5``.
+* JSON ``"Ensemble": {"Members": N, "Seed": s, "Days": d, "Noise": "philox"|"numpy", "Spinup": "shared"|"member"}``:
+  run N stochastic members (in-kernel Philox noise, or the reference's NumPy streams with member 0 on
+  ``SeedSequence(seed)`` and member k on ``spawn_key=(k,)``; one shared spin-up or one per member) and write the
+  per-row water-table mean / sigma to ``<Output_Name>_ensemble.h5``.
 """
 import sys
 from pathlib import Path
@@ -77,7 +79,9 @@ def _run_ensemble(params, water_data, output_name, ens, device):
     n_members = int(ens.get("Members", 4096))
     days = int(ens.get("Days", (forcing.dim_t - 1) // 48))
     rows = min(days * 48, forcing.dim_t - 1)
-    sim = EnsembleSimulation(cols, forcing, n_members, seed=int(ens.get("Seed", 0)), device=device)
+    sim = EnsembleSimulation(cols, forcing, n_members, seed=int(ens.get("Seed", 0)), device=device,
+                             noise=str(ens.get("Noise", "philox")).lower(),
+                             spinup=str(ens.get("Spinup", "shared")).lower())
     done = 0
     while done < rows:
         n = min(48 * 30, rows - done)

@@ -403,6 +403,46 @@ def test_full_size_day_properties(gpu):
     assert np.std(y[:, 10]) > 0.0                                                 # members really differ
 
 
+def test_baseline_config3_full_size_day(gpu):
+    """BASELINE.json config 3 at its FULL size on one GPU (262 144 members x D=300, one simulated day), checked
+    through size-independent properties: (i) any window of members equals a small stand-alone run of exactly those
+    global member ids, bit for bit (the Philox stream is keyed by the global id, the kernel has no cross-member
+    state); (ii) the int64 moments are exactly the sums of the per-member indices; (iii) a window checked
+    against the CPU oracle fed the same normals."""
+    _, cols, forcing = digest(300)
+    g = golden("g1_tables_300.npz")
+    N, D, rows = 262144, cols.dim_d, 48
+    st = gpu.EnsembleStepper(cols, forcing, N)
+    st.set_state(g["initial_cond"])
+    st.set_noise_philox(7, 0)
+    out = st.step_rows(1, rows, want_wtd=True)
+    m = st.moments()
+    w = out["wtd"].astype(np.int64)
+    assert np.array_equal(m[0, 1:1 + rows], np.full(rows, N))
+    assert np.array_equal(m[1, 1:1 + rows], w.sum(axis=1)) and np.array_equal(m[2, 1:1 + rows], (w ** 2).sum(axis=1))
+    assert w.min() >= 0 and w.max() <= D - 1
+    windows = {k: st.get_state(first=k, count=16) for k in (0, 131071, N - 16)}
+    for k, y_big in windows.items():
+        assert np.isfinite(y_big).all()
+        small = gpu.EnsembleStepper(cols, forcing, 16)
+        small.set_state(g["initial_cond"])
+        small.set_noise_philox(7, k)
+        o2 = small.step_rows(1, rows, want_wtd=True)
+        assert np.array_equal(small.get_state(), y_big), k
+        assert np.array_equal(o2["wtd"], out["wtd"][:, k:k + 16]), k
+        small.close()
+    # oracle on two members of the middle window, same normals (draw 0 = base, draw k = k-th refresh row)
+    o = _oracle(cols, forcing)
+    draws = np.cumsum(forcing.refresh)[1:1 + rows][forcing.refresh[1:1 + rows] == 1]
+    for k in (131071, 131075):
+        base = st.philox_normals(k, 0)
+        fresh = np.array([st.philox_normals(k, int(d)) for d in draws])
+        r = o.run(forcing, g["initial_cond"], base, fresh, 1, 1 + rows)
+        assert (out["wtd"][:, k] == r["wtd_est"][1:1 + rows]).mean() > 0.95
+        assert np.max(np.abs(windows[131071][k - 131071] - r["psi"]) / (1 + np.abs(r["psi"]))) < 1e-3
+    st.close()
+
+
 # ------------------------------------------------------------------------------- errors
 def test_error_paths(gpu):
     from hydromodel_amd._lib import HcError

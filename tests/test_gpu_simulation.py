@@ -117,3 +117,20 @@ def test_year_long_diagnostics_track_the_reference(year_run):
     assert np.max(np.abs(lf[:48] - g["lateral_flow"][:48]) / (1e-6 + g["lateral_flow"][:48])) < 5e-3
     assert abs(lf.sum() / g["lateral_flow"].sum() - 1) < 0.03
     assert np.corrcoef(lf, g["lateral_flow"])[0, 1] > 0.999
+
+
+def test_cli_ensemble_numpy_streams_and_member_spinup(tmp_path, monkeypatch, capsys):
+    from hydromodel_amd import cli
+    from hydromodel_amd.simulation import loadResults
+    params = default_parameters()
+    params["Site_Information"] = str(write_site_information(tmp_path / "site.json", {10: WELLS[1]}))
+    params["Data_Filename"] = str(write_forcing_csv(tmp_path / "forcing.csv", 1))
+    params["Ensemble"] = {"Members": 6, "Seed": 911, "Days": 1, "Noise": "NumPy", "Spinup": "Member"}
+    (tmp_path / "p.json").write_text(json.dumps(params))
+    monkeypatch.chdir(tmp_path)
+    cli.run_cli(["berkeley_hydro_main.py", "--params", str(tmp_path / "p.json")])
+    data = loadResults(tmp_path / "Sim_00_ensemble.h5")
+    assert int(data["members"]) == 6 and data["initial_cond"].shape == (6, 101)
+    assert np.array_equal(data["moments"][0, 1:49], np.full(48, 6))
+    # member 0 spun up with the reference's own first draw: the reference's initial condition
+    assert np.max(np.abs(data["initial_cond"][0] - golden("g5_traj_1.npz")["initial_cond"])) < 0.02
