@@ -164,7 +164,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{N} members/GPU x D={D}, {args.years}-yr half-hourly synthetic forcing "
+        "config": {"workload": ("BASELINE.json configs[2] (x8 GPUs = configs[3]): " if (N == 262144 and D == 300) else "")
+                               + f"{N} members/GPU x D={D}, {args.years}-yr half-hourly synthetic forcing "
                                f"({forcing.dim_t} rows), vrettas_fung + Stratified, ET+LF on; timed prefix = "
                                f"days {args.warmup + 1}..{args.warmup + args.steps}",
                    "members_per_gpu": N, "depth_nodes": D, "rows_per_step": ROWS_PER_DAY,
