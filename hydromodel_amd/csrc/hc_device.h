@@ -344,6 +344,9 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
 #ifndef HC_MODEL_BATCH
 #define HC_MODEL_BATCH 5
 #endif
+#ifndef HC_GENERIC_BATCH
+#define HC_GENERIC_BATCH 5
+#endif
 #define HC_V(...)                         \
     _Pragma("unroll") for (int c = 0; c < N; c++) { __VA_ARGS__; }
 template <int N, int SLOTS>
@@ -458,6 +461,162 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     HC_V(C[c] = (int(!sat[c]) & int(a[c] >= P.epsilon) & int(a[c] < INFINITY)) ? a[c] : P.epsilon)
 }
 
+// ---- vertical log / exp building blocks (same kernels as log_pos / exp_mid, applied to N cells per statement).
+// Scratch arrays _a, _b, _d, _e, _g, _h, _z, _w, _t1, _t2, _dk (double[N]), _lo (bool[N]), _ex (int[N]) must be in scope.
+#define HC_VLOG(OUT, IN)                                                                     \
+    HC_V(_b[c] = __builtin_amdgcn_frexp_mant(IN[c]))                                          \
+    HC_V(_ex[c] = __builtin_amdgcn_frexp_exp(IN[c]))                                          \
+    HC_V(_lo[c] = _b[c] < 0.70710678118654752440)                                             \
+    HC_V(_b[c] = _lo[c] ? _b[c] + _b[c] : _b[c])                                              \
+    HC_V(_ex[c] = _lo[c] ? _ex[c] - 1 : _ex[c])                                               \
+    HC_V(_h[c] = _b[c] - 1.0)                                                                 \
+    HC_V(_a[c] = 2.0 + _h[c])                                                                 \
+    HC_V(_b[c] = __builtin_amdgcn_rcp(_a[c]))                                                 \
+    HC_V(_d[c] = fma(-_a[c], _b[c], 1.0))                                                     \
+    HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))                                                    \
+    HC_V(_d[c] = fma(-_a[c], _b[c], 1.0))                                                     \
+    HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))                                                    \
+    HC_V(_d[c] = _h[c] * _b[c])                                                               \
+    HC_V(_e[c] = fma(-_a[c], _d[c], _h[c]))                                                   \
+    HC_V(_g[c] = fma(_e[c], _b[c], _d[c]))                                                    \
+    HC_V(_z[c] = _g[c] * _g[c])                                                               \
+    HC_V(_w[c] = _z[c] * _z[c])                                                               \
+    HC_V(_t1[c] = fma_s(_w[c], 1.531383769920937332e-01, 2.222219843214978396e-01))           \
+    HC_V(_t2[c] = fma_s(_w[c], 1.479819860511658591e-01, 1.818357216161805012e-01))           \
+    HC_V(_t1[c] = fma_s(_w[c], _t1[c], 3.999999999940941908e-01))                             \
+    HC_V(_t2[c] = fma_s(_w[c], _t2[c], 2.857142874366239149e-01))                             \
+    HC_V(_t1[c] = _w[c] * _t1[c])                                                             \
+    HC_V(_t2[c] = fma_s(_w[c], _t2[c], 6.666666666666735130e-01))                             \
+    HC_V(_t2[c] = _z[c] * _t2[c])                                                             \
+    HC_V(_a[c] = _t2[c] + _t1[c])                                                             \
+    HC_V(_e[c] = 0.5 * _h[c] * _h[c])                                                         \
+    HC_V(_dk[c] = (double)_ex[c])                                                             \
+    HC_V(_b[c] = _g[c] * (_e[c] + _a[c]) + _dk[c] * 1.90821492927058770002e-10)               \
+    HC_V(_b[c] = (_e[c] - _b[c]) - _h[c])                                                     \
+    HC_V(OUT[c] = _dk[c] * 6.93147180369123816490e-01 - _b[c])
+#define HC_VEXP(OUT, IN)                                                                     \
+    HC_V(_dk[c] = __builtin_rint(IN[c] * 1.4426950408889634))                                 \
+    HC_V(_a[c] = fma(-_dk[c], 6.93147180369123816490e-01, IN[c]))                             \
+    HC_V(_a[c] = fma(-_dk[c], 1.90821492927058770002e-10, _a[c]))                             \
+    HC_V(_b[c] = fma_s(_a[c], 1.0 / 6227020800.0, 1.0 / 479001600.0))                         \
+    HC_V(_b[c] = fma_s(_b[c], _a[c], 1.0 / 39916800.0))                                       \
+    HC_V(_b[c] = fma_s(_b[c], _a[c], 1.0 / 3628800.0))                                        \
+    HC_V(_b[c] = fma_s(_b[c], _a[c], 1.0 / 362880.0))                                         \
+    HC_V(_b[c] = fma_s(_b[c], _a[c], 1.0 / 40320.0))                                          \
+    HC_V(_b[c] = fma_s(_b[c], _a[c], 1.0 / 5040.0))                                           \
+    HC_V(_b[c] = fma_s(_b[c], _a[c], 1.0 / 720.0))                                            \
+    HC_V(_b[c] = fma_s(_b[c], _a[c], 1.0 / 120.0))                                            \
+    HC_V(_b[c] = fma_s(_b[c], _a[c], 1.0 / 24.0))                                             \
+    HC_V(_b[c] = fma_s(_b[c], _a[c], 1.0 / 6.0))                                              \
+    HC_V(_b[c] = fma(_b[c], _a[c], 0.5))                                                      \
+    HC_V(_b[c] = fma(_b[c], _a[c], 1.0))                                                      \
+    HC_V(_b[c] = fma(_b[c], _a[c], 1.0))                                                      \
+    HC_V(OUT[c] = ldexp(_b[c], (int)_dk[c]))
+
+// The cell model for arbitrary exponents (n > 1, lambda > 0; both plugins), vertical like model_cells_special.
+// Every power x^y is exp(y log x) on the in-house kernels above, with one log per distinct base (alpha|psi|, the
+// van Genuchten denominator, S_e); x = 0 is patched to the limit 0 (all exponents here are positive).  Against
+// libm's pow the result differs by |y log x| * 2^-53 ~ a few 1e-15 relative, two decades inside the 1e-11 parity
+// tier of theta, C and K; libm's pow costs ~3.6x the whole column-step.
+template <int N, int SLOTS>
+__device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const double *tab, int slot0,
+                                                    const double *psi, const double *rnd, double *theta, double *K,
+                                                    double *C, double *kbo, double *pfac)
+{
+    double _a[N], _b[N], _d[N], _e[N], _g[N], _h[N], _z[N], _w[N], _t1[N], _t2[N], _dk[N];
+    bool _lo[N];
+    int _ex[N];
+    double por[N], delta[N], ap[N], Lap[N], apn[N], x[N], s[N], Ls[N], y[N], u[N];
+    bool sat[N], apz[N], sz[N];
+    HC_V(por[c] = tab[T_POR * SLOTS + slot0 + c * WAVE])
+    HC_V(delta[c] = por[c] - P.theta_res)
+    HC_V(sat[c] = psi[c] >= P.psi_sat)
+    HC_V(ap[c] = P.alpha * fabs(psi[c]))
+    HC_V(apz[c] = ap[c] == 0.0)
+    HC_V(x[c] = apz[c] ? 1.0 : ap[c])
+    HC_VLOG(Lap, x)
+    // (alpha|psi|)^n, then pfac = (1 + that)^-m
+    HC_V(y[c] = P.n * Lap[c])
+    HC_VEXP(apn, y)
+    HC_V(apn[c] = apz[c] ? 0.0 : apn[c])
+    HC_V(x[c] = 1.0 + apn[c])
+    HC_VLOG(u, x)
+    HC_V(y[c] = -P.m * u[c])
+    HC_VEXP(u, y)
+    HC_V(pfac[c] = u[c])
+    HC_V(y[c] = fma(delta[c], pfac[c], P.theta_res))
+    HC_V(theta[c] = sat[c] ? por[c] : y[c])
+    // S_e = (theta - theta_res) / delta, clipped
+    HC_V(y[c] = theta[c] - P.theta_res)
+    HC_V(_b[c] = __builtin_amdgcn_rcp(delta[c]))
+    HC_V(_d[c] = fma(-delta[c], _b[c], 1.0))
+    HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))
+    HC_V(_d[c] = fma(-delta[c], _b[c], 1.0))
+    HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))
+    HC_V(_d[c] = y[c] * _b[c])
+    HC_V(_e[c] = fma(-delta[c], _d[c], y[c]))
+    HC_V(s[c] = fma(_e[c], _b[c], _d[c]))
+    HC_V(s[c] = fmin(fmax(s[c], 0.0), 1.0))
+    HC_V(sz[c] = s[c] == 0.0)
+    HC_V(x[c] = sz[c] ? 1.0 : s[c])
+    HC_VLOG(Ls, x)
+    if (P.model == 0) {
+        // K_bkg = exp(log m - Lt/2 + sqrt(Lt) eps), Lt = log(1 + sigma (1 - S_e) / m^2); K = S_e^lambda K_bkg
+        double invm2[N], logm[N], noisec[N], Lt[N];
+        HC_V(invm2[c] = tab[T_INVM2 * SLOTS + slot0 + c * WAVE])
+        HC_V(y[c] = P.sigma * (1.0 - s[c]))
+        HC_V(x[c] = fma(y[c], invm2[c], 1.0))
+        HC_VLOG(Lt, x)
+        HC_V(logm[c] = tab[T_LOGM * SLOTS + slot0 + c * WAVE])
+        HC_V(noisec[c] = tab[T_NOISEC * SLOTS + slot0 + c * WAVE])
+        HC_V(u[c] = sqrt_pos(Lt[c]))
+        HC_V(y[c] = fma(u[c], rnd[c], fma(-0.5, Lt[c], logm[c])))
+        HC_VEXP(u, y)
+        HC_V(kbo[c] = noisec[c] < 0.0 ? P.sat_soil : u[c])
+        if (P.lambda == 1.0) {
+            HC_V(u[c] = s[c])
+        } else {
+            HC_V(y[c] = P.lambda * Ls[c])
+            HC_VEXP(u, y)
+            HC_V(u[c] = sz[c] ? 0.0 : u[c])
+        }
+        HC_V(y[c] = u[c] * kbo[c])
+        HC_V(K[c] = sat[c] ? kbo[c] : y[c])
+    } else {
+        // vanGenuchten.py:91-98: K = K_sat sqrt(S_e) (1 - (1 - S_e^(1/m))^m)^n, capped at K_sat
+        double mth[N], v[N];
+        bool vz[N];
+        HC_V(y[c] = P.inv_m * Ls[c])
+        HC_VEXP(mth, y)
+        HC_V(mth[c] = sz[c] ? 0.0 : mth[c])
+        HC_V(v[c] = 1.0 - mth[c])
+        HC_V(vz[c] = !(v[c] > 0.0))
+        HC_V(x[c] = vz[c] ? 1.0 : v[c])
+        HC_VLOG(u, x)
+        HC_V(y[c] = P.m * u[c])
+        HC_VEXP(u, y)
+        HC_V(v[c] = 1.0 - (vz[c] ? 0.0 : u[c]))
+        HC_V(vz[c] = !(v[c] > 0.0))
+        HC_V(x[c] = vz[c] ? 1.0 : v[c])
+        HC_VLOG(u, x)
+        HC_V(y[c] = P.n * u[c])
+        HC_VEXP(u, y)
+        HC_V(u[c] = vz[c] ? 0.0 : u[c])
+        HC_V(kbo[c] = P.sat_soil)
+        HC_V(y[c] = fmin(P.sat_soil * sqrt_pos(s[c]) * u[c], P.sat_soil))
+        HC_V(K[c] = sat[c] ? kbo[c] : y[c])
+    }
+    // C = m n alpha delta S_e^(1/m + 1) (alpha|psi|)^(n-1)
+    HC_V(y[c] = (P.inv_m + 1.0) * Ls[c])
+    HC_VEXP(u, y)
+    HC_V(u[c] = sz[c] ? 0.0 : u[c])
+    HC_V(y[c] = (P.n - 1.0) * Lap[c])
+    HC_VEXP(x, y)
+    HC_V(x[c] = apz[c] ? 0.0 : x[c])
+    HC_V(y[c] = P.mn_alpha * delta[c] * u[c] * x[c])
+    HC_V(C[c] = (int(!sat[c]) & int(y[c] >= P.epsilon) & int(y[c] < INFINITY)) ? y[c] : P.epsilon)
+}
+
 // deepest cell index with pred true, or -1: cells are (lane, c) -> index lane*CPL + c
 template <int CPL>
 __device__ __forceinline__ int deepest_true(const bool (&pred)[CPL])
@@ -526,13 +685,17 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                                                                 th + NB * B, Kc + NB * B, Cc + NB * B, kbv + NB * B,
                                                                 pfv + NB * B);
         } else {
+            // generic exponents: batches of HC_GENERIC_BATCH cells (the working set of one cell is twice the special one's)
+            constexpr int B = HC_GENERIC_BATCH < CPL ? HC_GENERIC_BATCH : CPL;
+            constexpr int NB = CPL / B, REM = CPL - NB * B;
 #pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                const int slot = c * WAVE + lane;
-                model_cell<false>(P, ym[c], tab[T_POR * SLOTS + slot], 0.0, tab[T_LOGM * SLOTS + slot],
-                                  tab[T_INVM2 * SLOTS + slot], tab[T_NOISEC * SLOTS + slot], rnd[c], th[c], Kc[c],
-                                  Cc[c], kbv[c], pfv[c]);
-            }
+            for (int q = 0; q < NB; q++)
+                model_cells_generic<B, SLOTS>(P, tab, q * B * WAVE + lane, ym + q * B, rnd + q * B, th + q * B,
+                                              Kc + q * B, Cc + q * B, kbv + q * B, pfv + q * B);
+            if (REM > 0)
+                model_cells_generic<(REM > 0 ? REM : 1), SLOTS>(P, tab, NB * B * WAVE + lane, ym + NB * B, rnd + NB * B,
+                                                                th + NB * B, Kc + NB * B, Cc + NB * B, kbv + NB * B,
+                                                                pfv + NB * B);
         }
 #pragma unroll
         for (int c = 0; c < CPL; c++) {

@@ -299,8 +299,8 @@ int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, d
 // waves per workgroup per CPL: as many as the 160 KB of LDS admit (tables + per-wave vectors)
 #ifdef HC_DEV_ONLY_CPL5
 #define HC_DISPATCH(FN, ...)                                                            \
-    if (h->cpl == 5 && h->special) return FN<5, true, 4>(__VA_ARGS__);                  \
-    return fail(HC_ERR_UNSUPPORTED, "development build: CPL 5 / special only")
+    if (h->cpl == 5) return h->special ? FN<5, true, 4>(__VA_ARGS__) : FN<5, false, 4>(__VA_ARGS__); \
+    return fail(HC_ERR_UNSUPPORTED, "development build: CPL 5 only")
 #else
 #define HC_DISPATCH(FN, ...)                                                            \
     switch (h->cpl) {                                                                   \

@@ -1,0 +1,30 @@
+"""prof_generic.py against a development build: python tools/prof_generic_lib.py <lib.so> [n] [lam] [N] [D] [model]"""
+import os, sys, pathlib
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+from hydromodel_amd import _lib
+_lib.LIB_PATH = pathlib.Path(sys.argv[1]).resolve()
+sys.argv = [sys.argv[0]] + sys.argv[2:]
+import hashlib
+import numpy as np
+from hydromodel_amd.digest import ColumnTables, ForcingDigest
+from hydromodel_amd.ensemble import EnsembleSimulation
+from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+n = float(sys.argv[1]) if len(sys.argv) > 1 else 1.7
+lam = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
+D = int(sys.argv[4]) if len(sys.argv) > 4 else 300
+model = sys.argv[5] if len(sys.argv) > 5 else "vrettas_fung"
+params = default_parameters()
+params["Soil_Properties"]["n"] = n
+params["Hydraulic_Conductivity"]["Lambda_Exponent"] = lam
+params["Hydrological_Model"]["Name"] = model
+cols = ColumnTables(params, synthetic_well(D))
+forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+sim = EnsembleSimulation(cols, forcing, N, seed=1)
+sim.advance(48)
+sim.kernel_ms = 0.0
+sim.advance(96)
+print(f"{_lib.LIB_PATH.name} {model} n={n} lambda={lam} N={N} D={D}: {N * 2 / (sim.kernel_ms * 1e-3):.0f} column-days/s, "
+      f"counters {sim.stepper.counters()}, sha {hashlib.sha1(sim.stepper.get_state().tobytes()).hexdigest()[:10]}")
+sim.close()
