@@ -421,6 +421,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         if (!A.host_noise) nscale = io.nscale[member];
     }
     int fresh_seen = 0;
+    bool nz_is_base = false;     // V_NZ holds this member's base vector exactly as a fresh generation would give it
 
     for (int r = 0; r < A.n_rows; r++) {
         RowDev R;
@@ -444,7 +445,10 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         bool skip = (R.wtd_obs < 0) && !A.spinup;    // simulation.py:582-588
         if (!skip) {
             // ---- noise vector of this row -> V_NZ (simulation.py:592,599-602)
-            {
+            // The base vector stays in LDS from row to row: it is only rebuilt after a refresh row replaced it or a
+            // failed attempt damped it in place (x0.8 on the LDS copy and x0.8 on the scale round differently, and
+            // the result must not depend on where a launch boundary falls).  Box-Muller per row cost 2-3 % before.
+            if (refresh || !nz_is_base) {
                 const IoArgs io = load_const(A.io);
                 // Philox draws mirror the reference's order (simulation.py:426,561,601): the spin-up vector has
                 // its own index, 0 is the base vector, refresh row k uses draw k >= 1
@@ -465,6 +469,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     }
                     V[V_NZ * SLOTS + c * WAVE + lane] = z;
                 }
+                nz_is_base = !refresh;
             }
             __builtin_amdgcn_wave_barrier();
             int failed = 0;
@@ -1001,6 +1006,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 spin_mse = wave_sum(sq) / (double)D;
             }
             if (failed) {
+                nz_is_base = false;
                 const IoArgs io = load_const(A.io);
                 if (lane == 0) atomicAdd(&io.counters[1], (unsigned long long)failed);
                 if (!refresh && A.host_noise) {
