@@ -141,31 +141,57 @@ __device__ __forceinline__ void apply_RU(double *Dv, const double *ru, int lane)
     }
 }
 
-template <int CPL>
-__device__ __forceinline__ void change_D(double *Dv, double *ru, int order, double factor, int lane)
+// U of bdf.py change_D does not depend on the step factor: computed once per wave into ru[36..71]
+// (U[i][j] = prod_{q=1..i} (q - 1 - j) / q, U[0][:] = 1, U[i>=1][0] = 0)
+__device__ __forceinline__ void change_D_init(double *ru, int lane)
 {
     const int i = lane / 6, j = lane % 6;
-    double r = 1.0, u = 1.0;
+    double u = 1.0;
     if (lane < 36) {
         if (i >= 1) {
             if (j == 0) {
-                r = 0.0;
                 u = 0.0;
             } else {
-                for (int q = 1; q <= i; q++) {
-                    r *= ((double)(q - 1) - factor * (double)j) / (double)q;
-                    u *= ((double)(q - 1) - (double)j) / (double)q;
-                }
+                for (int q = 1; q <= i; q++) u *= ((double)(q - 1) - (double)j) / (double)q;
             }
         }
-        ru[lane] = r;
         ru[36 + lane] = u;
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+template <int CPL>
+__device__ __forceinline__ void change_D(double *Dv, double *ru, int order, double factor, int lane)
+{
+    // R[i][j] = prod_{q=1..i} (q - 1 - factor j) / q on lanes 0..35 (cumprod of bdf.py compute_R), RU = R U on the
+    // same lanes with all twelve operands read before the first multiply, then D[:order+1] = RU^T D[:order+1]
+    const int i = lane / 6, j = lane % 6;
     if (lane < 36) {
-        double s = 0.0;
-        for (int k = 0; k <= order; k++) s += ru[i * 6 + k] * ru[36 + k * 6 + j];
-        ru[72 + lane] = s;
+        double r = 1.0;
+        const double fj = factor * (double)j;
+#pragma unroll
+        for (int q = 1; q <= 5; q++) {
+            const double t = r * fast_div((double)(q - 1) - fj, (double)q);
+            r = q <= i ? t : r;
+        }
+        r = (i >= 1 && j == 0) ? 0.0 : r;
+        ru[lane] = r;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+        double ra[6], ub[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            ra[k] = ru[i * 6 + k];
+            ub[k] = ru[36 + k * 6 + j];
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const double t = fma(ra[k], ub[k], acc);
+            acc = k <= order ? t : acc;
+        }
+        ru[72 + lane] = acc;
     }
     __builtin_amdgcn_wave_barrier();
     switch (order) {
@@ -389,6 +415,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     int prof_slot = 31;
 #endif
     double *Dv = V + V_D0 * SLOTS;
+    change_D_init(ru, lane);
     const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
 
