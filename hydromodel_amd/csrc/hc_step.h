@@ -536,6 +536,9 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     scl[c] = 1.0;
                 }
                 int phase = PH_F0;
+                // column parameters: one scalar-memory read per attempt.  (Per RHS evaluation the lone wave sat out
+                // the load latency 24 times per row; for the kernel's lifetime they cost ~60 SGPRs, see DESIGN.md.)
+                const ColumnDev P = load_const(A.P);
                 int guard = 0;                       // every wave must reach an exit: bound the phase loop
 #ifdef HC_PROFILE
                 unsigned long long prof_t = clock64();
@@ -554,7 +557,6 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         phase = C_FAIL;
                     }
                     if (phase < C_SUCCESS) {
-                        const ColumnDev P = load_const(A.P);
                         rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf);
 #ifdef HC_PROFILE
                         const unsigned long long now = clock64();
