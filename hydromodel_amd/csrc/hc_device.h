@@ -660,16 +660,19 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         double kbv[CPL], pfv[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-            const int i = lane * CPL + c;
+            // No mask for cells beyond the last midpoint: y is 0 in the padding slots, the tables hold benign values
+            // there, and C / flux / sink of those cells are zeroed before the assembly below.  Only the virtual
+            // top-node cell (last slot of lane 63) needs its own argument.
             const double yn = (c + 1 < CPL) ? y[c + 1 < CPL ? c + 1 : c] : y_nf;
-            const bool vmid = i < D - 1;
-            const bool vtop = (c == CPL - 1) && (lane == WAVE - 1);
             double psi = 0.5 * (y[c] + yn);
-            double dy = (yn - y[c]) * P.inv_dz;
-            psi = vmid ? psi : (vtop ? y_top : -100.0);
-            dy = vmid ? dy : 0.0;
+            if (c == CPL - 1) psi = (lane == WAVE - 1) ? y_top : psi;
             ym[c] = psi;
-            dym[c] = dy;
+            {
+                // the gradient is a rounded value of its own, as in the reference (richards_pde.py:566): it must not
+                // be fused into the flux K (dy - 1) further down
+#pragma clang fp contract(off)
+                dym[c] = (yn - y[c]) * P.inv_dz;
+            }
         }
         if (SPECIAL) {
             // batches of HC_MODEL_BATCH cells: enough independent chains to hide the fp64 latency, few

@@ -104,11 +104,15 @@ template <int CPL>
 __device__ __forceinline__ double rms_ratio(const double (&x)[CPL], const double (&is)[CPL], int lane, int D,
                                             double inv_sqrt_d)
 {
+    // no node mask: every vector this is applied to is exactly 0 in the padding slots beyond the grid (state,
+    // differences and dy/dt are kept 0 there), and 1/scale is finite there
+    (void)lane;
+    (void)D;
     double acc = 0.0;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const double r = x[c] * is[c];
-        acc += (lane * CPL + c < D) ? r * r : 0.0;
+        acc = fma(r, r, acc);
     }
     return sqrt_pos(wave_sum(acc)) * inv_sqrt_d;
 }
@@ -337,9 +341,10 @@ __device__ __forceinline__ void lu_solve(const TriLU<CPL> &F, double (&x)[CPL], 
 #pragma unroll
     for (int s = 0; s < 6; s++) {
         const int d = 1 << s;
-        double Rm = bpermute_d((lane - d) * 4, Rr), Rp = bpermute_d((lane + d) * 4, Rr);
-        Rm = lane >= d ? Rm : 0.0;
-        Rp = lane + d < WAVE ? Rp : 0.0;
+        // A lane without a neighbour at distance d reads some other lane's (finite) value through the wrapped
+        // permute address, but its coefficient is an exact zero there: lu_factor masks the neighbour's pivot to 1 and
+        // its coupling to 0, and the couplings of the outermost 2^s lanes have been multiplied by that 0 since.
+        const double Rm = bpermute_d((lane - d) * 4, Rr), Rp = bpermute_d((lane + d) * 4, Rr);
         Rr = Rr + F.al[s] * Rm + F.ga[s] * Rp;
     }
     const double xe = Rr * F.invB;
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         {
                             double dy[CPL];
 #pragma unroll
-                            for (int c = 0; c < CPL; c++) dy[c] = vnode[c] ? cc * f[c] - psiv[c] - dd[c] : 0.0;
+                            for (int c = 0; c < CPL; c++) dy[c] = cc * f[c] - psiv[c] - dd[c];   // 0 in the padding slots
                             HC_STAMP(20);
                             lu_solve<CPL>(F, dy, lane);
                             HC_STAMP(21);
