@@ -19,8 +19,9 @@ namespace hc {
 constexpr int WAVE = 64;
 
 // slot tables staged in LDS, [NTAB][64*CPL] doubles
-enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, T_INVDELTA, T_INVD1, NTAB };
-// T_INVDELTA = 1/(por - theta_res), T_INVD1 = 1/(por - wlt) (a zero denominator counts as 1)
+enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, T_VALID, T_INVD1, NTAB };
+// T_VALID = 1.0 in the slots of the D-1 midpoints, 0.0 beyond (a lane mask as data: a mask proper is an SGPR pair
+// the compiler spills and reloads with two v_readlane per use), T_INVD1 = 1/(por - wlt) (a zero denominator counts as 1)
 // per-slot integer tables, [NGTAB][64*CPL]
 enum { G_SELF = 0, G_PREV, G_NEXT, NGTAB };
 
@@ -884,9 +885,9 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     // :119 and :155 after cancelling the signs; padding nodes come out as 0/1 = 0.
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
-        const bool vmid = lane * CPL + c < D - 1;
-        Cc[c] = vmid ? Cc[c] : 0.0;
-        fl[c] = vmid ? fl[c] : 0.0;
+        const double valid = tab[T_VALID * SLOTS + c * WAVE + lane];    // 1.0 / 0.0; the cell values are finite
+        Cc[c] *= valid;
+        fl[c] *= valid;
     }
     const double cP0 = shfl_up1(Cc[CPL - 1], lane, 0.0);
     const double sP0 = shfl_up1(sk[CPL - 1], lane, 0.0);

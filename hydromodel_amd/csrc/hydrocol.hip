@@ -468,7 +468,7 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
         tab[(size_t)T_LOGM * S + slot] = std::log(mk);
         tab[(size_t)T_INVM2 * S + slot] = 1.0 / (mk * mk);
         tab[(size_t)T_NOISEC * S + slot] = noisec;
-        tab[(size_t)T_INVDELTA * S + slot] = 1.0 / (por - p->theta_res);
+        tab[(size_t)T_VALID * S + slot] = 1.0;
         const double d1 = por - wlt;                       // tree_roots.py:235-238
         tab[(size_t)T_INVD1 * S + slot] = 1.0 / (d1 == 0.0 ? 1.0 : d1);
     };
@@ -480,6 +480,7 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
                     mid_tabs[4 * M + i], mid_tabs[5 * M + i]);
             else
                 put(slot, 0.3, 0.2, 0.1, 0.0, 1.0, 0.0);    // padding cell: benign, results masked
+            if (i >= M) tab[(size_t)T_VALID * S + slot] = 0.0;
             if (i < D) {
                 gt[(size_t)G_SELF * S + slot] = groups[i];
                 gt[(size_t)G_PREV * S + slot] = i >= 1 ? groups[i - 1] : -1;
@@ -488,6 +489,7 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
         }
     // virtual top-node cell in the always-free slot (lane 63, c = cpl-1)
     put((cpl - 1) * WAVE + (WAVE - 1), node_tabs[0], 0.2, 0.1, 0.0, node_tabs[D + 0], node_tabs[2 * D + 0]);
+    tab[(size_t)T_VALID * S + (cpl - 1) * WAVE + (WAVE - 1)] = 0.0;   // its C / flux never enter the assembly
     if (h->tab.ensure(tab.size()) || h->gtab.ensure(gt.size()) || h->node_tabs.ensure((size_t)3 * D))
         return HC_ERR_DEVICE;
     HIP_TRY(hipMemcpy(h->tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
