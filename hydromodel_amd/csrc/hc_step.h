@@ -281,7 +281,7 @@ __device__ __forceinline__ void lu_factor(TriLU<CPL> &F, const double (&jl)[CPL]
     F.wf[0] = 0.0;
 #pragma unroll
     for (int c = 1; c < CPL; c++) {
-        const double w = a[c] / b[c - 1];
+        const double w = fast_div(a[c], b[c - 1]);
         F.wf[c] = w;
         F.l[c] = -w * F.l[c - 1];
         b[c] -= w * cu[c - 1];
@@ -295,7 +295,7 @@ __device__ __forceinline__ void lu_factor(TriLU<CPL> &F, const double (&jl)[CPL]
     }
 #pragma unroll
     for (int c = CPL - 3; c >= 0; c--) {
-        const double w = cu[c] / b[c + 1];
+        const double w = fast_div(cu[c], b[c + 1]);
         F.wb[c] = w;
         F.l[c] -= w * F.l[c + 1];
         F.u[c] = -w * F.u[c + 1];
@@ -304,11 +304,11 @@ __device__ __forceinline__ void lu_factor(TriLU<CPL> &F, const double (&jl)[CPL]
     const double nl = shfl_down1(F.l[0], lane, 0.0);
     const double nb = shfl_down1(b[0], lane, 1.0);
     const double nu = shfl_down1(F.u[0], lane, 0.0);
-    const double w = F.u[CPL - 1] / nb;
+    const double w = fast_div(F.u[CPL - 1], nb);
     F.wx = w;
     double L = F.l[CPL - 1], B = b[CPL - 1] - w * nl, U = -w * nu;
 #pragma unroll
-    for (int c = 0; c < CPL; c++) F.ib[c] = 1.0 / b[c];
+    for (int c = 0; c < CPL; c++) F.ib[c] = fast_div(1.0, b[c]);
     // parallel cyclic reduction on the 64 chunk-end unknowns
 #pragma unroll
     for (int s = 0; s < 6; s++) {
@@ -319,14 +319,14 @@ __device__ __forceinline__ void lu_factor(TriLU<CPL> &F, const double (&jl)[CPL]
         const bool hm = lane >= d, hp = lane + d < WAVE;
         Bm = hm ? Bm : 1.0; Um = hm ? Um : 0.0; Lm = hm ? Lm : 0.0;
         Bp = hp ? Bp : 1.0; Lp = hp ? Lp : 0.0; Up = hp ? Up : 0.0;
-        const double al = -L / Bm, ga = -U / Bp;
+        const double al = fast_div(-L, Bm), ga = fast_div(-U, Bp);
         F.al[s] = al;
         F.ga[s] = ga;
         B = B + al * Um + ga * Lp;
         L = al * Lm;
         U = ga * Up;
     }
-    F.invB = 1.0 / B;
+    F.invB = fast_div(1.0, B);
 }
 
 template <int CPL>
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             y0v[c] = ycur[c];
                             Dv[1 * SLOTS + slot] = f[c];      // parked here until h_abs is known
                             V[V_FP * SLOTS + slot] = f[c];    // base f of the first Jacobian
-                            scl[c] = 1.0 / (ATOL + fabs(y0v[c]) * RTOL);
+                            scl[c] = fast_div(1.0, ATOL + fabs(y0v[c]) * RTOL);
                         }
                         const double d0 = rms_ratio<CPL>(y0v, scl, lane, D, inv_sqrt_d);
                         const double d1 = rms_ratio<CPL>(f, scl, lane, D, inv_sqrt_d);
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             // scipy: `if not np.all(np.isfinite(f)): break`.  A non-finite f makes the solve and its
                             // norm non-finite, and the iterate is left untouched either way.
                             const bool have_rate = dy_norm_old >= 0.0;
-                            const double rate = have_rate ? dy_norm / dy_norm_old : 0.0;
+                            const double rate = have_rate ? fast_div(dy_norm, dy_norm_old) : 0.0;
                             double rp = rate;
                             for (int q = 1; q < NEWTON_MAXITER - newton_k; q++) rp *= rate;
                             // rate**(4-k) / (1 - rate) * dy_norm > tol, with 0 <= rate < 1 on the right-hand branch
@@ -831,9 +831,9 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             // J row i: (f_new[i] - f[i]) / h[column]
                             const double hU = c == 0 ? hU0 : hj[c > 0 ? c - 1 : 0];
                             const double hD = c == CPL - 1 ? hD0 : hj[c < CPL - 1 ? c + 1 : c];
-                            njl[c] = hasU && vnode[c] ? (jl[c] - fb[c]) / hU : 0.0;
-                            njd[c] = vnode[c] ? (jd[c] - fb[c]) / hj[c] : 0.0;
-                            nju[c] = hasD ? (ju[c] - fb[c]) / hD : 0.0;
+                            njl[c] = hasU && vnode[c] ? fast_div(jl[c] - fb[c], hU) : 0.0;
+                            njd[c] = vnode[c] ? fast_div(jd[c] - fb[c], hj[c]) : 0.0;
+                            nju[c] = hasD ? fast_div(ju[c] - fb[c], hD) : 0.0;
                         }
                         if (jac_stage == 0 && __any(small_bits != 0)) {
                             // rare: some column moved f by less than EPS^0.875 of its size -> retry those columns
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         double e[CPL];
 #pragma unroll
                         for (int c = 0; c < CPL; c++) {
-                            scl[c] = 1.0 / (ATOL + RTOL * fabs(ycur[c]));
+                            scl[c] = fast_div(1.0, ATOL + RTOL * fabs(ycur[c]));
                             e[c] = ec * dd[c];
                         }
                         error_norm = rms_ratio<CPL>(e, scl, lane, D, inv_sqrt_d);
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                                 default: predict<CPL, 5>(Dv, lane, inv_alpha, yp, psiv); break;
                             }
 #pragma unroll
-                            for (int c = 0; c < CPL; c++) scl[c] = 1.0 / (ATOL + RTOL * fabs(yp[c]));
+                            for (int c = 0; c < CPL; c++) scl[c] = fast_div(1.0, ATOL + RTOL * fabs(yp[c]));
                             cc = h / alpha_k(order);
                             phase = C_NEWTON_BEGIN;
                         }
