@@ -641,34 +641,39 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             HC_STAMP(22);
                             // scipy: `if not np.all(np.isfinite(f)): break`.  A non-finite f makes the solve and its
                             // norm non-finite, and the iterate is left untouched either way.
+                            // The decisions are evaluated as flags (no short-circuit control flow: every `&&` on these
+                            // wave-uniform doubles costs an exec-mask save / branch / restore triple otherwise).
                             const bool have_rate = dy_norm_old >= 0.0;
                             const double rate = have_rate ? fast_div(dy_norm, dy_norm_old) : 0.0;
-                            double rp = rate;
-                            for (int q = 1; q < NEWTON_MAXITER - newton_k; q++) rp *= rate;
+                            // rate ** (NEWTON_MAXITER - k), k = 1, 2, 3 (iteration 0 has no rate): products in the
+                            // order the power loop took them
+                            const double r2 = rate * rate;
+                            const double rp = newton_k <= 1 ? r2 * rate : (newton_k == 2 ? r2 : rate);
+                            const double slack = NEWTON_TOL * (1.0 - rate);
                             // rate**(4-k) / (1 - rate) * dy_norm > tol, with 0 <= rate < 1 on the right-hand branch
-                            if (!(dy_norm < INFINITY) ||
-                                (have_rate && (rate >= 1.0 || rp * dy_norm > NEWTON_TOL * (1.0 - rate)))) {
-                                failed_newton = true;
-                            } else {
+                            const int fail = int(!(dy_norm < INFINITY)) |
+                                             (int(have_rate) & (int(rate >= 1.0) | int(rp * dy_norm > slack)));
+                            const int conv = int(!fail) & (int(dy_norm == 0.0) | (int(have_rate) & int(rate * dy_norm < slack)));
+                            if (!fail) {
 #pragma unroll
                                 for (int c = 0; c < CPL; c++) {
                                     ycur[c] += dy[c];
                                     dd[c] += dy[c];
                                 }
-                                if (dy_norm == 0.0 || (have_rate && rate * dy_norm < NEWTON_TOL * (1.0 - rate))) {
-                                    converged = true;
-                                } else {
-                                    dy_norm_old = dy_norm;
-                                    newton_k++;
-                                    if (newton_k == NEWTON_MAXITER) failed_newton = true;
-                                }
                             }
+                            const int more = int(!fail) & int(!conv);
+                            dy_norm_old = more ? dy_norm : dy_norm_old;
+                            newton_k += more;
+                            converged = conv;
+                            failed_newton = fail | (more & int(newton_k == NEWTON_MAXITER));
                         }
                         if (converged) {
                             n_iter = newton_k + 1;
                             phase = C_ERR_TEST;
                         } else if (failed_newton) {
                             phase = C_NEWTON_FAIL;
+                        } else {
+                            continue;      // next Newton iterate: straight back to the RHS site
                         }
                     }
                     if (phase == C_NEWTON_FAIL) {
