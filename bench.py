@@ -34,13 +34,13 @@ sys.path.insert(0, str(REPO))
 ROWS_PER_DAY = 48
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per member per 48-row launch at D=300, from rocprofv3 PMC passes on this launch shape
-# (profiles/r01_pmc_fetch_size_c.csv, r01_pmc_write_size_c.csv; N = 65 536): 2 x FETCH_SIZE (gfx950 counts
+# (profiles/r01_pmc_fetch_size_f.csv, r01_pmc_write_size_f.csv; N = 65 536): 2 x FETCH_SIZE (gfx950 counts
 # half of the fetched bytes -- confirmed on a calibration dispatch that only loads and stores psi)
-# + WRITE_SIZE = (2 x 80 670.9 + 182 353.8) KiB / 65 536 members.
-PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 = (2 * 80670.9375 + 182353.75) * 1024.0 / 65536.0
+# + WRITE_SIZE = (2 x 80 754.1 + 183 726.8) KiB / 65 536 members.
+PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 = (2 * 80754.125 + 183726.8125) * 1024.0 / 65536.0
 # fp64 work per column-step at D=300 from rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 (wave instructions
-# per column-step: 2 740 / 4 182 / 8 733 / 827; x64 lanes, FMA = 2 flop) -- the secondary, honest roofline
-PMC_F64_FLOP_PER_COLUMN_STEP_D300 = (2740 + 4182 + 827 + 2 * 8733) * 64.0
+# per column-step: 2 241 / 3 990 / 8 487 / 745; x64 lanes, FMA = 2 flop) -- the secondary, honest roofline
+PMC_F64_FLOP_PER_COLUMN_STEP_D300 = (2241 + 3990 + 745 + 2 * 8487) * 64.0
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
 
 
@@ -175,7 +175,7 @@ def main():
                      "traffic": (PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 * N
                                  if (D == 300 and abs(rows_per_launch - 48) < 1e-9) else None),
                      "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same launch shape "
-                                       "(profiles/r01_pmc_*_size_c.csv), scaled by members; psi stays in LDS for the "
+                                       "(profiles/r01_pmc_*_size_f.csv), scaled by members; psi stays in LDS for the "
                                        "48 rows of a launch, so HBM sees ~1/44 of the algorithmic bytes",
                      "kernel": "hc::step_kernel", "launch_ms": launch_ms, "launches": sim.launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
