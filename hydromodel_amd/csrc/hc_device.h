@@ -375,7 +375,8 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     HC_V(pfac[c] = fma(d[c], e[c], b[c]))
     HC_V(a[c] = fma(delta[c], pfac[c], P.theta_res))
     HC_V(theta[c] = sat[c] ? por[c] : a[c])
-    // s = (theta - theta_res) / delta
+    // s = (theta - theta_res) / delta   (the next table read is issued here, a division ahead of its use)
+    HC_V(invm2[c] = tab[T_INVM2 * SLOTS + slot0 + c * WAVE])
     HC_V(a[c] = theta[c] - P.theta_res)
     HC_V(b[c] = __builtin_amdgcn_rcp(delta[c]))
     HC_V(d[c] = fma(-delta[c], b[c], 1.0))
@@ -387,7 +388,6 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     HC_V(s[c] = fma(e[c], b[c], d[c]))
     HC_V(s[c] = fmin(fmax(s[c], 0.0), 1.0))
     // t = 1 + sigma (1 - s) / m^2;  Lt = log_pos(t)
-    HC_V(invm2[c] = tab[T_INVM2 * SLOTS + slot0 + c * WAVE])
     HC_V(a[c] = P.sigma * (1.0 - s[c]))
     HC_V(a[c] = fma(a[c], invm2[c], 1.0))
     HC_V(b[c] = __builtin_amdgcn_frexp_mant(a[c]))
