@@ -314,11 +314,12 @@ __device__ __forceinline__ void lu_factor(TriLU<CPL> &F, const double (&jl)[CPL]
     for (int s = 0; s < 6; s++) {
         const int d = 1 << s;
         const int am = (lane - d) * 4, ap = (lane + d) * 4;
-        double Bm = bpermute_d(am, B), Um = bpermute_d(am, U), Lm = bpermute_d(am, L);
-        double Bp = bpermute_d(ap, B), Lp = bpermute_d(ap, L), Up = bpermute_d(ap, U);
-        const bool hm = lane >= d, hp = lane + d < WAVE;
-        Bm = hm ? Bm : 1.0; Um = hm ? Um : 0.0; Lm = hm ? Lm : 0.0;
-        Bp = hp ? Bp : 1.0; Lp = hp ? Lp : 0.0; Up = hp ? Up : 0.0;
+        // A lane without a neighbour at distance d reads another lane's (finite, non-zero pivot) values through
+        // the wrapped permute address; its own coupling L (or U) is an exact zero by then -- lane 0 has no lower
+        // coupling, lane 63 no upper one, and each stage multiplies the couplings of the next 2^s lanes by that
+        // zero -- so al (ga) and everything it multiplies vanish without a mask.
+        const double Bm = bpermute_d(am, B), Um = bpermute_d(am, U), Lm = bpermute_d(am, L);
+        const double Bp = bpermute_d(ap, B), Lp = bpermute_d(ap, L), Up = bpermute_d(ap, U);
         const double al = fast_div(-L, Bm), ga = fast_div(-U, Bp);
         F.al[s] = al;
         F.ga[s] = ga;
