@@ -284,7 +284,9 @@ int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, d
 {
     auto kern = rhs_kernel<CPL, SPECIAL, WPB>;
 #ifdef HC_PROFILE
-    const size_t lds = step_lds_bytes(CPL, WPB);   // same occupancy as the step kernel
+    // diagnostic build: the step kernel's occupancy (one workgroup per CU) unless HYDROCOL_RHS_LDS_KB says otherwise
+    size_t lds = step_lds_bytes(CPL, WPB);
+    if (const char *e = getenv("HYDROCOL_RHS_LDS_KB")) lds = std::max(rhs_lds_bytes(CPL, WPB), (size_t)atoll(e) * 1024);
 #else
     const size_t lds = rhs_lds_bytes(CPL, WPB);
 #endif
@@ -300,6 +302,7 @@ int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, d
 #ifdef HC_DEV_ONLY_CPL5
 #define HC_DISPATCH(FN, ...)                                                            \
     if (h->cpl == 5) return h->special ? FN<5, true, 4>(__VA_ARGS__) : FN<5, false, 4>(__VA_ARGS__); \
+    if (h->cpl == 3 && h->special) return FN<3, true, 4>(__VA_ARGS__);                  \
     return fail(HC_ERR_UNSUPPORTED, "development build: CPL 5 only")
 #else
 #define HC_DISPATCH(FN, ...)                                                            \
