@@ -76,6 +76,8 @@ struct hc_handle {
     bool special = false;
     DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
     DevBuf<int> spin_iters;
+    DevBuf<double> trace;        // diagnostic builds only
+    bool strict_guard = false;   // HYDROCOL_STRICT_GUARD=1: a tripped iteration guard fails the call
     DevBuf<int> gtab, wtd_obs, draw_idx, stats, scratch_i;
     DevBuf<unsigned char> daylight, refresh;
     DevBuf<unsigned short> wtd_u16;
@@ -366,6 +368,13 @@ int fill_args(hc_handle *h, StepArgs &A)
     io.seed = h->seed;
     io.counters = h->counters.p;
     io.queue = h->counters.p + 63;
+#ifdef HC_PROFILE
+    if (getenv("HYDROCOL_DEBUG_TRACE")) {
+        if (h->trace.ensure((size_t)1 + 6 * HC_TRACE_N)) return HC_ERR_DEVICE;
+        hipMemset(h->trace.p, 0, ((size_t)1 + 6 * HC_TRACE_N) * 8);
+        io.trace = h->trace.p;
+    }
+#endif
     return HC_OK;
 }
 
@@ -403,6 +412,7 @@ int hc_create(int device_ordinal, hc_handle **out)
     }
     const char *rpl = getenv("HYDROCOL_ROWS_PER_LAUNCH");
     if (rpl && atoi(rpl) > 0) h->rows_per_launch = atoi(rpl);
+    if (const char *sg = getenv("HYDROCOL_STRICT_GUARD")) h->strict_guard = atoi(sg) != 0;
     const char *jr = getenv("HYDROCOL_DEBUG_JAC_REJECT");   // test hook: exercises num_jac's retry branch
     if (jr && atof(jr) > 0.0) h->jac_reject = atof(jr);
     *out = h;
@@ -418,6 +428,7 @@ int hc_destroy(hc_handle *h)
     h->base.release(); h->nscale.release(); h->fresh.release(); h->psi_rows.release(); h->scratch_d.release();
     h->diag.release();
     h->spin_iters.release();
+    h->trace.release();
     h->gtab.release(); h->wtd_obs.release(); h->draw_idx.release(); h->stats.release(); h->scratch_i.release();
     h->Pdev.release(); h->iodev.release();
     h->daylight.release(); h->refresh.release(); h->wtd_u16.release(); h->moments.release(); h->counters.release();
@@ -718,9 +729,11 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
     }
     unsigned long long cnt[4];
     HIP_TRY(hipMemcpy(cnt, h->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
-    if (cnt[2] != 0)
-        return fail(HC_ERR_DEVICE, "%llu BDF attempts hit the kernel's iteration guard (non-terminating step control)",
-                    cnt[2]);
+    // An attempt that exhausts the kernel's iteration budget is abandoned like a solve that gave up (the x0.8
+    // retry rule applies); it is counted ([2], last place in [3]) and only fatal on request.
+    if (cnt[2] != 0 && h->strict_guard)
+        return fail(HC_ERR_DEVICE, "%llu BDF attempts hit the kernel's iteration guard (last: member %llu, row %llu)",
+                    cnt[2], cnt[3] >> 24, cnt[3] & 0xFFFFFFull);
     return HC_OK;
 }
 
@@ -756,9 +769,11 @@ int hc_spinup(hc_handle *h, hc_spinup_args *a)
     a->kernel_ms = ms;
     unsigned long long cnt[4];
     HIP_TRY(hipMemcpy(cnt, h->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
-    if (cnt[2] != 0)
-        return fail(HC_ERR_DEVICE, "%llu BDF attempts hit the kernel's iteration guard (non-terminating step control)",
-                    cnt[2]);
+    // An attempt that exhausts the kernel's iteration budget is abandoned like a solve that gave up (the x0.8
+    // retry rule applies); it is counted ([2], last place in [3]) and only fatal on request.
+    if (cnt[2] != 0 && h->strict_guard)
+        return fail(HC_ERR_DEVICE, "%llu BDF attempts hit the kernel's iteration guard (last: member %llu, row %llu)",
+                    cnt[2], cnt[3] >> 24, cnt[3] & 0xFFFFFFull);
     return HC_OK;
 }
 
@@ -772,6 +787,14 @@ int hc_get_counters(hc_handle *h, uint64_t *out4)
 }
 
 #ifdef HC_PROFILE
+extern "C" int hc_debug_trace(hc_handle *h, double *out, int64_t n)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!h->trace.p) return fail(HC_ERR_ARG, "no trace (set HYDROCOL_DEBUG_TRACE)");
+    HIP_TRY(hipMemcpy(out, h->trace.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return HC_OK;
+}
 extern "C" int hc_debug_profile(hc_handle *h, uint64_t *out32)
 {
     HIP_TRY(hipSetDevice(h->device));

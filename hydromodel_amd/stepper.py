@@ -143,7 +143,8 @@ class EnsembleStepper:
         """{'jac_retry': ..., 'failed_attempts': ..., 'guard_trips': ...} since the handle was created."""
         out = (C.c_uint64 * 4)()
         L.check(self.lib.hc_get_counters(self.h, out))
-        return {"jac_retry": int(out[0]), "failed_attempts": int(out[1]), "guard_trips": int(out[2])}
+        return {"jac_retry": int(out[0]), "failed_attempts": int(out[1]), "guard_trips": int(out[2]),
+                "guard_last_member": int(out[3]) >> 24, "guard_last_row": int(out[3]) & 0xFFFFFF}
 
     def moments(self):
         m = np.zeros((3, self.T), dtype=np.int64)

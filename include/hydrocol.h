@@ -137,8 +137,10 @@ typedef struct {
 int hc_spinup(hc_handle *h, hc_spinup_args *a);
 int hc_synchronize(hc_handle *h);
 /* event counters since hc_create: [0] FD-Jacobian passes that took num_jac's "difference too small ->
- * retry with a 10x step" branch, [1] failed BDF attempts (each scales the noise by 0.8), [2] kernel
- * iteration-guard trips (always 0; hc_step_rows fails otherwise), [3] reserved */
+ * retry with a 10x step" branch, [1] failed BDF attempts (each scales the noise by 0.8), [2] attempts abandoned
+ * by the kernel's iteration budget (60 000 phase steps, ~2 400x a typical attempt; handled like a solve that gave
+ * up; with HYDROCOL_STRICT_GUARD=1 in the environment hc_step_rows / hc_spinup fail instead), [3] where the
+ * last of those happened: global member id << 24 | forcing row */
 int hc_get_counters(hc_handle *h, uint64_t *out4);
 
 /* moments: [3][n_forcing_rows] int64 = count, sum(idx), sum(idx^2) of wtd_est over members */

@@ -230,6 +230,8 @@ void ho_last_arg_out(double *out2)
     out2[1] = g_last_arg_out[1];
 }
 
+#define HO_MAX_EVALS_PER_ATTEMPT 20000
+
 /* ---- RichardsPDE.pde_fun, ref: richards_pde.py:172-395 ------------------------------- */
 static void pde_fun(const ho_column *c, const ho_row *r, int view, const double *y, const double *dydz,
                     const double *n_rnd, double *C, double *sink, double *flux, double *tr_lf)
@@ -687,6 +689,13 @@ static int bdf_integrate(bdf_t *b, double t0, double tf, const double *y0, doubl
         double error_norm = 0.0, safety = 0.0;
         while (!step_accepted) {
             if (h_abs < min_step) {
+                ok = 0;
+                goto done;
+            }
+            /* Work budget of one attempt, mirroring the kernel's iteration budget (hc_step.h MAX_PHASE_ITERATIONS):
+             * on a state sliding along a discontinuity of the RHS the step controller cycles for ever with
+             * h ~ 1e-11 (SciPy's BDF has no exit there either).  RHS evaluations incl. the 5 per FD Jacobian. */
+            if (b->nfev + 5 * b->njev > HO_MAX_EVALS_PER_ATTEMPT) {
                 ok = 0;
                 goto done;
             }

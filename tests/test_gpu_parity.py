@@ -918,3 +918,37 @@ def test_ensemble_mean_sigma_match_the_oracle_over_a_month(gpu):
     assert dmu.max() <= 0.5 * cols.dz and dsg.max() <= 0.5 * cols.dz, (dmu.max(), dsg.max())
     assert (dmu <= 0.05 * cols.dz).mean() >= 0.90 and (dsg <= 0.05 * cols.dz).mean() >= 0.85
     assert dmu[:96].max() == 0.0 and dsg[:96].max() == 0.0       # the first two days: identical integer moments
+
+
+def test_attempt_that_chatters_on_a_discontinuity_is_abandoned_and_retried(gpu):
+    """A row found in the 262 144-member run (member 165 062, row 2 140 of the 1-year forcing, tools/guard_hunt.py):
+    from this state the BDF step controller slides along a discontinuity of the RHS -- Newton only converges for
+    h ~ 1e-11, the controller cycles halve / accept twice / x10 and time advances ~1e-11 per cycle.  SciPy's
+    algorithm has no exit there; the CPU oracle does the same on most 1e-13 perturbations of this input.  Kernel and
+    oracle give such an attempt a work budget, then apply the reference's failure rule (noise x0.8, retry)."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    cols = ColumnTables(params, synthetic_well(300))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+    g = golden("chatter_row_300.npz")
+    row = int(g["row"])
+    st = gpu.EnsembleStepper(cols, forcing, 1)
+    st.set_state(g["y_before"])
+    st.set_noise_host(g["z"][None, :])
+    out = st.step_rows(row, 1, fresh_noise=np.zeros((0,)), want_stats=True)
+    c = st.counters()
+    nfev, attempts = int(out["stats"][0, 0, 0]), int(out["stats"][0, 0, 4])
+    y = st.get_state()[0]
+    base_after = st.get_noise_base()[0]
+    assert np.isfinite(y).all()
+    assert c["guard_trips"] >= 1 and attempts == c["guard_trips"] + 1 and c["guard_last_row"] == row
+    assert 20000 * c["guard_trips"] < nfev + 5 * int(out["stats"][0, 0, 1]) + 10 < 20000 * (c["guard_trips"] + 1)
+    assert out["kernel_ms"] < 3000.0                                   # bounded: ~0.1 s per abandoned attempt
+    assert np.allclose(base_after, g["z"] * 0.8 ** c["guard_trips"], rtol=1e-15)    # the x0.8 rule, in place
+    # the oracle on the same input happens to get through in one attempt; both answers are valid rtol = 1e-3 solves
+    o = _oracle(cols, forcing)
+    yo, so, _, _ = o.solve_row(_row(forcing, row), row - 1, row, g["y_before"], g["z"].copy())
+    assert so["success"] == 1
+    assert np.max(np.abs(y - yo) / (1 + np.abs(yo))) < 5e-2
+    st.close()

@@ -242,3 +242,28 @@ def test_plugin_and_flag_variants_replay(fname, well, model, n_rows):
     assert np.median(errs) < 1e-10
     assert np.quantile(errs, 0.8 if hlift else 0.9) < 1e-5
     assert errs.max() < (0.2 if hlift else 5e-2)
+
+
+def test_work_budget_ends_a_chattering_attempt():
+    """tests/golden/chatter_row_300.npz (found by tools/guard_hunt.py): most 1e-13 perturbations of this input send the
+    BDF step controller into an endless halve / accept / x10 cycle at h ~ 1e-11 on a discontinuity of the RHS.  The
+    oracle's work budget (HO_MAX_EVALS_PER_ATTEMPT, mirroring the kernel's) ends the attempt; the x0.8 retry gets through."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    cols = ColumnTables(params, synthetic_well(300))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+    o = Oracle(cols, forcing.surface_evap)
+    g = golden("chatter_row_300.npz")
+    row = int(g["row"])
+    r = Oracle.row(forcing.precip[row], forcing.atm[row], forcing.daylight[row], forcing.wtd_obs[row])
+    stuck = 0
+    for seed in range(1, 7):
+        y0 = g["y_before"] * (1.0 + 1e-13 * np.random.default_rng(seed).standard_normal(300))
+        z = g["z"].copy()
+        y1, so, z_out, _ = o.solve_row(r, row - 1, row, y0, z)
+        assert np.isfinite(y1).all() and so["success"] == 1
+        if so["attempts"] > 1:       # gave up at least once (budget, or the ordinary h < min_step exit): x0.8 per failure
+            assert np.allclose(z_out, g["z"] * 0.8 ** (so["attempts"] - 1), rtol=1e-15)
+            stuck += so["nfev"] > 5000
+    assert stuck >= 2

@@ -32,7 +32,7 @@ c = sim.stepper.counters()
 assert (m[0, 1:] == N).all()
 print(f"N={N} D={cols.dim_d} rows={T - 1} wall={wall:.1f}s kernel={sim.kernel_ms / 1e3:.1f}s "
       f"column-days/s={N * (T - 1) / 48 / (sim.kernel_ms / 1e3):.0f}")
-print("counters: jac_retry_passes", c["jac_retry"], "failed_attempts", c["failed_attempts"], "guard_trips",
+print("counters: jac_retry_passes", c["jac_retry"], "failed_attempts", c["failed_attempts"], "attempts abandoned by the iteration budget",
       c["guard_trips"], f"(failed attempts per member-year: {c['failed_attempts'] / N / years:.2f})")
 print(f"wtd mean over the run: {np.nanmean(mean_cm[1:]):.1f} cm, ensemble sigma mean {np.nanmean(std_cm[1:]):.2f} cm, "
       f"max sigma {np.nanmax(std_cm[1:]):.2f} cm; final-row mean {mean_cm[-1]:.1f} sigma {std_cm[-1]:.2f}")
