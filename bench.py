@@ -40,9 +40,10 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # half of the fetched bytes -- confirmed on a calibration dispatch that only loads and stores psi)
 # + WRITE_SIZE = (2 x 80 754.1 + 183 726.8) KiB / 65 536 members.
 PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 = (2 * 80754.125 + 183726.8125) * 1024.0 / 65536.0
-# fp64 work per column-step at D=300 from rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 (wave instructions
-# per column-step: 2 241 / 3 990 / 8 487 / 745; x64 lanes, FMA = 2 flop) -- the secondary, honest roofline
-PMC_F64_FLOP_PER_COLUMN_STEP_D300 = (2241 + 3990 + 745 + 2 * 8487) * 64.0
+# fp64 work per column-step at D=300 from rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 summed over the 31 launches of
+# this very bench (profiles/r01_pmc_sq_f64_bench_g.csv; wave instructions per column-step: 2 019.5 / 3 674.7 / 7 846.5 /
+# 685.3; x64 lanes, FMA = 2 flop) -- the secondary, honest roofline.  Days 2-3 alone need 8 % more (r01_pmc_sq_f64_f.csv).
+PMC_F64_FLOP_PER_COLUMN_STEP_D300 = (2019.5 + 3674.7 + 685.3 + 2 * 7846.5) * 64.0
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
 
 
