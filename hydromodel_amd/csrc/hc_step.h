@@ -30,7 +30,11 @@ constexpr double NUM_JAC_DIFF_BIG = 0.0001220703125;
 constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 
 // per-wave LDS vectors (each 64*CPL doubles)
-enum { V_Y = 0, V_FP, V_NZ, V_FAC, V_D0, NVEC = V_D0 + MAX_ORDER + 3 };
+// per-wave LDS vectors.  V_NZ (the row's noise vector) comes last so that the deep-column variants can leave it out:
+// beyond CPL = 6 every vector costs a wave of occupancy, and the noise can be re-read / regenerated per attempt.
+enum { V_Y = 0, V_FP, V_FAC, V_D0, V_NZ = V_D0 + MAX_ORDER + 3, NVEC = V_NZ + 1 };
+__host__ __device__ constexpr bool nz_in_lds(int cpl) { return cpl <= 6 || cpl == 8; }
+__host__ __device__ constexpr int nvec_of(int cpl) { return nz_in_lds(cpl) ? NVEC : NVEC - 1; }
 #ifdef HC_PROFILE
 constexpr int WAVE_SCRATCH = 192;
 #else
@@ -84,6 +88,7 @@ struct StepArgs {
     // spin-up with the per-member stop rule of simulation.py:468 evaluated in the kernel (hc_spinup)
     int spin_stop;
     double spin_zwtd, spin_z0, spin_dz;
+    int max_phase_iterations; // MAX_PHASE_ITERATIONS (test hook: HYDROCOL_DEBUG_MAX_ITER lowers it to force abandoned attempts)
 };
 
 // Uniform struct load from device memory through the constant address space (s_load_dwordxN).  The empty
@@ -409,18 +414,20 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     constexpr int SLOTS = WAVE * CPL;
     extern __shared__ double lds[];
     double *tab = lds;
-    int *gtab = reinterpret_cast<int *>(tab + NTAB * SLOTS);
+    signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB * SLOTS);     // group ids < 16: a byte each
     double *wave_base = reinterpret_cast<double *>(gtab + 4 * SLOTS);
+    constexpr bool NZ_LDS = nz_in_lds(CPL);
+    constexpr int NVEC_K = nvec_of(CPL);
     for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
-    for (int k = threadIdx.x; k < NGTAB * SLOTS; k += WPB * WAVE) gtab[k] = A.gtab[k];
+    for (int k = threadIdx.x; k < NGTAB * SLOTS; k += WPB * WAVE) gtab[k] = (signed char)A.gtab[k];
     __syncthreads();
 
     // No barrier below this line: every wave is an independent worker.  The grid is persistent (one
     // workgroup per CU); a wave that finishes its member takes the next one from a device-wide ticket,
     // so members of unequal cost never leave SIMDs idle behind a slow neighbour.  Exit: ticket >= N.
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    double *V = wave_base + (size_t)wave * (NVEC * SLOTS + WAVE_SCRATCH);
-    double *ru = V + NVEC * SLOTS;
+    double *V = wave_base + (size_t)wave * (NVEC_K * SLOTS + WAVE_SCRATCH);
+    double *ru = V + NVEC_K * SLOTS;
     double *row0 = ru + 108;                    // f_new[group][row 0], <= 16 groups
     int *flags_lds = reinterpret_cast<int *>(ru + 124);   // per-lane column flags of the FD-Jacobian retry pass
 #ifdef HC_PROFILE
@@ -489,12 +496,17 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
             // The base vector stays in LDS from row to row: it is only rebuilt after a refresh row replaced it or a
             // failed attempt damped it in place (x0.8 on the LDS copy and x0.8 on the scale round differently, and
             // the result must not depend on where a launch boundary falls).  Box-Muller per row cost 2-3 % before.
-            if (refresh || !nz_is_base) {
+            unsigned draw_row = 0u;
+            {
+                const IoArgs io = load_const(A.io);
+                draw_row = A.spinup ? PHILOX_DRAW_SPINUP : ((refresh && !A.host_noise) ? (unsigned)io.draw_idx[row] : 0u);
+            }
+            const double nscale_row = nscale;      // damping of the base vector when the row starts
+            if (NZ_LDS && (refresh || !nz_is_base)) {
                 const IoArgs io = load_const(A.io);
                 // Philox draws mirror the reference's order (simulation.py:426,561,601): the spin-up vector has
                 // its own index, 0 is the base vector, refresh row k uses draw k >= 1
-                const unsigned draw = A.spinup ? PHILOX_DRAW_SPINUP
-                                               : ((refresh && !A.host_noise) ? (unsigned)io.draw_idx[row] : 0u);
+                const unsigned draw = draw_row;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
                     const int i = lane * CPL + c;
@@ -528,7 +540,22 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     const int i = lane * CPL + c;
                     int idx = i >= 1 ? i - 1 : 0;
                     idx = (i < D - 1) ? idx : 0;
-                    const double z = V[V_NZ * SLOTS + (idx % CPL) * WAVE + idx / CPL];
+                    double z;
+                    if (NZ_LDS) {
+                        z = V[V_NZ * SLOTS + (idx % CPL) * WAVE + idx / CPL];
+                    } else {
+                        // deep columns: no noise vector in LDS -- value of node idx for this attempt, read / generated
+                        // again and damped in the order the in-place rule takes (x0.8 per failed attempt of this row)
+                        const IoArgs io = load_const(A.io);
+                        if (A.host_noise) {
+                            z = refresh ? io.fresh[((size_t)fresh_seen * A.n_members + member) * D + idx]
+                                        : io.base_noise[member * D + idx];
+                        } else {
+                            z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), draw_row, (unsigned)idx);
+                            z = refresh ? z : z * nscale_row;
+                        }
+                        for (int k = 0; k < failed; k++) z *= 0.8;
+                    }
                     rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * z;
                 }
                 // ================= one BDF integration over [t0, tf] =================
@@ -581,7 +608,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         }
                     }
 #endif
-                    if (++guard > MAX_PHASE_ITERATIONS) {
+                    if (++guard > A.max_phase_iterations) {
                         if (lane == 0) {
                             const IoArgs iog = load_const(A.io);
                             atomicAdd(&iog.counters[2], 1ull);
@@ -1060,7 +1087,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 // failed attempt: n_rnd *= 0.8 in place (richards_pde.py:522); restart from y0
                 failed++;
 #pragma unroll
-                for (int c = 0; c < CPL; c++) V[V_NZ * SLOTS + c * WAVE + lane] *= 0.8;
+                for (int c = 0; c < CPL; c++)
+                    if (NZ_LDS) V[V_NZ * SLOTS + c * WAVE + lane] *= 0.8;
                 if (!refresh) nscale *= 0.8;
                 __builtin_amdgcn_wave_barrier();
                 if (attempts >= 5) break;
@@ -1080,8 +1108,18 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 if (lane == 0) atomicAdd(&io.counters[1], (unsigned long long)failed);
                 if (!refresh && A.host_noise) {
 #pragma unroll
-                    for (int c = 0; c < CPL; c++)
-                        if (vnode[c]) io.base_noise[member * D + lane * CPL + c] = V[V_NZ * SLOTS + c * WAVE + lane];
+                    for (int c = 0; c < CPL; c++) {
+                        if (!vnode[c]) continue;
+                        double z;
+                        if (NZ_LDS) {
+                            z = V[V_NZ * SLOTS + c * WAVE + lane];
+                        } else {
+                            z = io.base_noise[member * D + lane * CPL + c];
+                            for (int k = 0; k < failed; k++) z *= 0.8;
+                        }
+                        io.base_noise[member * D + lane * CPL + c] = z;
+                    }
+                    if (!NZ_LDS) __threadfence_block();   // the next row's reads of the neighbour lane's nodes see it
                 }
             }
             if (refresh) fresh_seen++;

@@ -77,6 +77,7 @@ struct hc_handle {
     DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
     DevBuf<int> spin_iters;
     DevBuf<double> trace;        // diagnostic builds only
+    int max_phase_iterations = MAX_PHASE_ITERATIONS;
     bool strict_guard = false;   // HYDROCOL_STRICT_GUARD=1: a tripped iteration guard fails the call
     DevBuf<int> gtab, wtd_obs, draw_idx, stats, scratch_i;
     DevBuf<unsigned char> daylight, refresh;
@@ -257,7 +258,7 @@ namespace {
 size_t step_lds_bytes(int cpl, int wpb)
 {
     const size_t slots = (size_t)WAVE * cpl;
-    return NTAB * slots * 8 + 4 * slots * 4 + (size_t)wpb * (NVEC * slots + WAVE_SCRATCH) * 8;
+    return NTAB * slots * 8 + 4 * slots * 1 + (size_t)wpb * ((size_t)nvec_of(cpl) * slots + WAVE_SCRATCH) * 8;
 }
 size_t rhs_lds_bytes(int cpl, int wpb)
 {
@@ -314,10 +315,10 @@ int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, d
         case 4: return h->special ? FN<4, true, 4>(__VA_ARGS__) : FN<4, false, 4>(__VA_ARGS__); \
         case 5: return h->special ? FN<5, true, 4>(__VA_ARGS__) : FN<5, false, 4>(__VA_ARGS__); \
         case 6: return h->special ? FN<6, true, 3>(__VA_ARGS__) : FN<6, false, 3>(__VA_ARGS__); \
-        case 7: return h->special ? FN<7, true, 2>(__VA_ARGS__) : FN<7, false, 2>(__VA_ARGS__); \
+        case 7: return h->special ? FN<7, true, 3>(__VA_ARGS__) : FN<7, false, 3>(__VA_ARGS__); \
         case 8: return h->special ? FN<8, true, 2>(__VA_ARGS__) : FN<8, false, 2>(__VA_ARGS__); \
-        case 9: return h->special ? FN<9, true, 1>(__VA_ARGS__) : FN<9, false, 1>(__VA_ARGS__); \
-        case 10: return h->special ? FN<10, true, 1>(__VA_ARGS__) : FN<10, false, 1>(__VA_ARGS__); \
+        case 9: return h->special ? FN<9, true, 2>(__VA_ARGS__) : FN<9, false, 2>(__VA_ARGS__); \
+        case 10: return h->special ? FN<10, true, 2>(__VA_ARGS__) : FN<10, false, 2>(__VA_ARGS__); \
         default: break;                                                                 \
     }                                                                                   \
     return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= %d", h->p.dim_d, h->cpl, \
@@ -355,6 +356,7 @@ int fill_args(hc_handle *h, StepArgs &A)
     A.host_noise = h->philox ? 0 : 1;
     A.psi_sat = h->P.psi_sat;
     A.jac_reject = h->jac_reject;
+    A.max_phase_iterations = h->max_phase_iterations;
     io.psi = h->psi.p;
     io.base_noise = h->philox ? nullptr : h->base.p;
     io.nscale = h->nscale.p;
@@ -413,6 +415,8 @@ int hc_create(int device_ordinal, hc_handle **out)
     const char *rpl = getenv("HYDROCOL_ROWS_PER_LAUNCH");
     if (rpl && atoi(rpl) > 0) h->rows_per_launch = atoi(rpl);
     if (const char *sg = getenv("HYDROCOL_STRICT_GUARD")) h->strict_guard = atoi(sg) != 0;
+    if (const char *mi = getenv("HYDROCOL_DEBUG_MAX_ITER"))    // test hook: forces abandoned attempts
+        if (atoi(mi) > 0) h->max_phase_iterations = atoi(mi);
     const char *jr = getenv("HYDROCOL_DEBUG_JAC_REJECT");   // test hook: exercises num_jac's retry branch
     if (jr && atof(jr) > 0.0) h->jac_reject = atof(jr);
     *out = h;

@@ -140,7 +140,9 @@ int hc_synchronize(hc_handle *h);
  * retry with a 10x step" branch, [1] failed BDF attempts (each scales the noise by 0.8), [2] attempts abandoned
  * by the kernel's iteration budget (60 000 phase steps, ~2 400x a typical attempt; handled like a solve that gave
  * up; with HYDROCOL_STRICT_GUARD=1 in the environment hc_step_rows / hc_spinup fail instead), [3] where the
- * last of those happened: global member id << 24 | forcing row */
+ * last of those happened: global member id << 24 | forcing row.
+ * Test hooks read from the environment at hc_create: HYDROCOL_DEBUG_MAX_ITER (lowers that budget to force abandoned
+ * attempts), HYDROCOL_DEBUG_JAC_REJECT (raises num_jac's retry threshold), HYDROCOL_ROWS_PER_LAUNCH. */
 int hc_get_counters(hc_handle *h, uint64_t *out4);
 
 /* moments: [3][n_forcing_rows] int64 = count, sum(idx), sum(idx^2) of wtd_est over members */

@@ -952,3 +952,52 @@ def test_attempt_that_chatters_on_a_discontinuity_is_abandoned_and_retried(gpu):
     assert so["success"] == 1
     assert np.max(np.abs(y - yo) / (1 + np.abs(yo))) < 5e-2
     st.close()
+
+
+@pytest.mark.parametrize("dim_d", [300, 401, 581])
+def test_retry_rule_on_every_noise_layout(gpu, dim_d, monkeypatch):
+    """The x0.8 rule with the noise vector in LDS (D <= 384) and without it (deep columns re-read / regenerate the
+    vector per attempt): a test hook lowers the iteration budget so that every attempt of a row is abandoned."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import pressure_head
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    cols = ColumnTables(params, synthetic_well(dim_d))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+    y0, _ = pressure_head(cols, cols.por_raw)
+    N, D = 3, cols.dim_d
+    rng = np.random.default_rng(4)
+    base = rng.standard_normal((N, D))
+    # a regular run first: the state after 4 rows, nothing abandoned
+    ref = gpu.EnsembleStepper(cols, forcing, N)
+    ref.set_state(y0); ref.set_noise_host(base)
+    ref.step_rows(1, 4, fresh_noise=np.zeros((0,)))
+    y_ref = ref.get_state()
+    assert ref.counters()["failed_attempts"] == 0 and np.array_equal(ref.get_noise_base(), base)
+    ref.close()
+    monkeypatch.setenv("HYDROCOL_DEBUG_MAX_ITER", "3")
+    st = gpu.EnsembleStepper(cols, forcing, N)
+    st.set_state(y0); st.set_noise_host(base)
+    out = st.step_rows(1, 2, fresh_noise=np.zeros((0,)), want_stats=True)
+    c = st.counters()
+    assert (out["stats"][:, :, 4] == 5).all() and c["guard_trips"] == 2 * N * 5 and c["failed_attempts"] == 2 * N * 5
+    # two rows x five abandoned attempts: the base vector carries x0.8 ten times, applied one at a time
+    expect = base.copy()
+    for _ in range(10):
+        expect = expect * 0.8
+    assert np.array_equal(st.get_noise_base(), expect)
+    assert np.array_equal(st.get_state(), np.tile(y0, (N, 1)))          # no step was accepted: y0 is returned
+    # a refresh row: the fresh vector lives one row, the base vector is untouched
+    row = 48
+    fresh = rng.standard_normal((1, N, D))
+    before = st.get_noise_base()
+    st.step_rows(row, 1, fresh_noise=fresh)
+    assert np.array_equal(st.get_noise_base(), before)
+    st.close()
+    # Philox mode: the same rule through the per-member scale; afterwards a regular run proceeds
+    ph = gpu.EnsembleStepper(cols, forcing, N)
+    ph.set_state(y0); ph.set_noise_philox(5, 0)
+    ph.step_rows(1, 1)
+    assert ph.counters()["failed_attempts"] == N * 5
+    ph.close()
+    assert np.isfinite(y_ref).all()
