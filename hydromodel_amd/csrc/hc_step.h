@@ -1019,7 +1019,11 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     if (phase == C_STEP_BEGIN) {
                         HC_STAMP(C_STEP_BEGIN);
                         // _step_impl entry
-                        min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+                        // nextafter(t, +inf) for the finite t >= 0 of this integrator: one integer increment of the bit
+                        // pattern (the smallest subnormal from 0), not a libm call per step
+                        const double t_up = t == 0.0 ? 4.9406564584124654e-324
+                                                     : __longlong_as_double(__double_as_longlong(t) + 1ll);
+                        min_step = 10.0 * fabs(t_up - t);
                         if (h_abs < min_step) {
                             change_D<CPL>(Dv, ru, order, min_step / h_abs, lane);
                             h_abs = min_step;
