@@ -172,11 +172,24 @@ def porosity_profiles(z_grid, layers, theta, soil, p_model):
     q_sat = np.minimum(np.maximum(q_sat, theta.min), theta.max)
 
     def fun_wrc(psi):
-        return theta.res + (q_sat - theta.res) / (1.0 + (soil.alpha * psi) ** soil.n) ** soil.m
+        # porosity.py:172-173 writes (alpha * psi) ** n with the signed psi.  For the even integer n the reference
+        # ships (n = 2) that equals (alpha * |psi|) ** n bit for bit.  For any other n and psi < 0 (the wilting point,
+        # -1500 cm by default) the reference's expression is complex, Porosity returns complex128 profiles and the
+        # first RHS evaluation raises "setting an array element with a sequence" (richards_pde.py:119): the reference
+        # cannot run there.  EXTENSION, no reference oracle: the retention curve is evaluated on |psi|, the form
+        # vrettas_fung.py:115 itself uses, so every n > 1 has a real field capacity / wilting point.
+        base = soil.alpha * psi
+        if not (float(soil.n) == 2.0 * round(float(soil.n) / 2.0)):
+            base = np.abs(base)
+        return theta.res + (q_sat - theta.res) / (1.0 + base ** soil.n) ** soil.m
 
-    with np.errstate(invalid="ignore"):
-        field_cap = np.maximum(fun_wrc(theta.flc), theta.res)
-        wilting = np.minimum(fun_wrc(theta.wlt), field_cap)
+    field_cap = np.maximum(fun_wrc(theta.flc), theta.res)
+    wilting = np.minimum(fun_wrc(theta.wlt), field_cap)
+    if np.iscomplexobj(field_cap) or np.iscomplexobj(wilting) or not (
+            np.all(np.isfinite(field_cap)) and np.all(np.isfinite(wilting))):
+        raise ValueError(" Porosity: field capacity / wilting point profiles are not real and finite.")
+    if np.any(wilting < theta.res):
+        raise ValueError(" Porosity: wilting point profile falls below the residual water content.")
     return q_sat.flatten(), field_cap, wilting
 
 

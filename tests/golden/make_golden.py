@@ -12,6 +12,7 @@ Usage:
     python tests/golden/make_golden.py static     # G1-G4,G6  (fast, ~1 min)
     python tests/golden/make_golden.py traj 101   # G5 trajectory, well 1 (D=101), ~8 min
     python tests/golden/make_golden.py traj 200   # G5 trajectory, synthetic D=200, ~8 min
+    python tests/golden/make_golden.py points     # G1-G4 at three non-default (a0, psi_sat, lambda, sigma) points, ~1 min
     python tests/golden/make_golden.py short      # first days of vanGenuchten / HLIFT / ET+LF-off runs, ~1 min
 
 Vector families:
@@ -74,7 +75,13 @@ def _wells():
             200: synthetic_well(200), 300: synthetic_well(300)}
 
 
-def _setup(well_no, tmp, n_years=1, model="vrettas_fung", flags=None, quiet=True):
+# Non-default parameter points the reference CAN run (n = 2; see DESIGN.md §8 for why n must be an even integer there):
+# BASELINE config 5 sweeps (n, a0, psi_sat); lambda and sigma ride along to pin the generic-exponent kernel.
+with open(HERE / "points.json") as _fh:
+    POINTS = json.load(_fh)
+
+
+def _setup(well_no, tmp, n_years=1, model="vrettas_fung", flags=None, quiet=True, overrides=None):
     site = write_site_information(Path(tmp) / "site.json", _wells())
     params = default_parameters()
     params["Site_Information"] = str(site)
@@ -82,6 +89,8 @@ def _setup(well_no, tmp, n_years=1, model="vrettas_fung", flags=None, quiet=True
     params["Hydrological_Model"]["Name"] = model
     if flags:
         params["Simulation_Flags"].update(flags)
+    for section, values in (overrides or {}).items():
+        params[section].update(values)
     data = synthetic_forcing_frame(n_years)
     sim = Simulation(f"golden_{well_no}", seed=SEED)
     if quiet:
@@ -466,6 +475,13 @@ def main(argv):
                 _save(f"g2_pointwise_{well}.npz", g2_pointwise(sim))
                 _save(f"g34_states_{well}.npz", g34_states(sim))
             _save("g6_rng.npz", g6_rng())
+        elif mode == "points":
+            # G1-G4 at non-default parameter points (n = 2), synthetic well D=200
+            for tag, ov in POINTS.items():
+                sim, _, _ = _setup(200, tmp, overrides=ov)
+                _save(f"g1p_tables_{tag}.npz", g1_tables(sim))
+                _save(f"g2p_pointwise_{tag}.npz", g2_pointwise(sim))
+                _save(f"g34p_states_{tag}.npz", g34_states(sim))
         elif mode == "traj":
             well = int(argv[2])
             _save(f"g5_traj_{well}.npz", g5_trajectory(well, tmp))

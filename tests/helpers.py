@@ -29,6 +29,25 @@ def digest(well, model="vrettas_fung", n_years=1):
 
 
 @lru_cache(maxsize=None)
+def points():
+    """Non-default parameter points of tests/golden/points.json (fixtures g1p/g2p/g34p, synthetic well D=200)."""
+    import json
+    with open(GOLDEN / "points.json") as fh:
+        return json.load(fh)
+
+
+@lru_cache(maxsize=None)
+def digest_point(tag, model="vrettas_fung", well=200):
+    params = default_parameters()
+    params["Hydrological_Model"]["Name"] = model
+    for section, values in points()[tag].items():
+        params[section].update(values)
+    cols = ColumnTables(params, WELLS[well])
+    forcing = ForcingDigest(params, forcing_frame(1), cols)
+    return params, cols, forcing
+
+
+@lru_cache(maxsize=None)
 def golden(name):
     return dict(np.load(GOLDEN / name))
 

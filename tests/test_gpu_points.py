@@ -1,0 +1,131 @@
+"""GPU parity at non-default parameter points (BASELINE config 5), against the reference's own outputs.
+
+Fixtures g2p / g34p (tests/golden/points.json; ``make_golden.py points``) were produced by the reference at three
+points with n = 2 and a0, psi_sat, lambda, sigma, K_sat away from their defaults; lambda != 1 sends the kernel through
+``model_cells_generic``, lambda = 1 keeps the specialised cell model with other constants and tables.
+Tolerances as in tests/test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from helpers import digest_point, golden, points, rel_err
+
+pytestmark = pytest.mark.gpu
+TAGS = sorted(points())
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    import __graft_entry__ as ge
+    ge.build()
+    from hydromodel_amd import stepper
+    return stepper
+
+
+@pytest.mark.parametrize("tag", TAGS)
+@pytest.mark.parametrize("model,key", [("vrettas_fung", "vf"), ("vanGenuchten", "vg")])
+def test_plugin_at_the_nodes_matches_the_reference(gpu, tag, model, key):
+    _, cols, forcing = digest_point(tag, model)
+    g = golden(f"g2p_pointwise_{tag}.npz")
+    names = ("sweep", "ic", "moist", "dry")
+    Y = np.array([g[f"psi_{n}"] for n in names])
+    st = gpu.EnsembleStepper(cols, forcing, len(Y))
+    st.set_state(Y)
+    st.set_noise_host(np.tile(g["n_rnd"], (len(Y), 1)))
+    out = st.model_nodes()
+    for k, name in enumerate(names):
+        assert rel_err(out["theta"][k], g[f"{key}_{name}_node_q"]) < 1e-12
+        assert rel_err(out["K_bkg"][k], g[f"{key}_{name}_node_kbkg"]) < 1e-9
+        assert rel_err(out["K"][k], g[f"{key}_{name}_node_K"]) < 1e-9
+        assert rel_err(out["C"][k], g[f"{key}_{name}_node_C"], 1e-7) < 1e-11
+        assert abs(out["q_inf_max"][k] - float(g[f"{key}_{name}_node_qinf"])) < 1e-9
+    st.close()
+
+
+def _rows(forcing):
+    day = int(np.argmax((forcing.daylight == 1) & (forcing.precip == 0.0)))
+    night = int(np.argmax((forcing.daylight == 0) & (forcing.precip == 0.0) & (np.arange(forcing.dim_t) > 0)))
+    return day, night
+
+
+CASES = (("night_dry", "night", None), ("day_dry", "day", None), ("lf_active", "night", None),
+         ("rough_night", "night", None), ("dry_profile_day", "day", None), ("no_et_day", "day", {"ET": False}),
+         ("no_lf", "night", {"LF": False}))
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_rhs_at_the_point_matches_the_reference(gpu, tag):
+    _, cols, forcing = digest_point(tag)
+    g = golden(f"g34p_states_{tag}.npz")
+    day, night = _rows(forcing)
+    assert forcing.atm[day] == float(g["day_dry_atm"])
+    for name, when, flags in CASES:
+        st = gpu.EnsembleStepper(cols, forcing, 1, flags=flags)
+        st.set_state(g[f"{name}_y"][None, :])
+        st.set_noise_host(g["n_rnd"][None, :])
+        dydt, aux = st.rhs(day if when == "day" else night, want_aux=True)
+        assert rel_err(dydt[0], g[f"{name}_dydt"]) < 1e-7, name
+        assert rel_err(aux["c"][0][1:], g[f"{name}_mid_c"], 1e-7) < 1e-11, name
+        assert rel_err(aux["f"][0][1:], g[f"{name}_mid_f"]) < 1e-11, name
+        assert rel_err(aux["s"][0][1:], g[f"{name}_mid_s"], 1e-3) < 1e-11, name
+        assert abs(aux["pL"][0] - g[f"{name}_bc"][0]) < 1e-12, name
+        st.close()
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_single_row_at_the_point_matches_the_reference(gpu, tag):
+    """G4 at the point: the reference's solve of constructed states (t_span (7, 8); a forcing row with the same
+    arguments differs only through min_step, which never binds)."""
+    _, cols, forcing = digest_point(tag)
+    g = golden(f"g34p_states_{tag}.npz")
+    day, night = _rows(forcing)
+    same = total = loose = 0
+    for name, when, flags in CASES:
+        ref_stats = g[f"{name}_solve_stats"]
+        if ref_stats.shape[0] != 1 or ref_stats[0, 0] > 300:
+            continue
+        st = gpu.EnsembleStepper(cols, forcing, 1, flags=flags)
+        st.set_state(g[f"{name}_y"][None, :])
+        st.set_noise_host(g["n_rnd"][None, :])
+        out = st.step_rows(day if when == "day" else night, 1, fresh_noise=np.zeros((0,)), want_stats=True)
+        y1 = st.get_state()[0]
+        st.close()
+        ry = g[f"{name}_solve_y"]
+        err = np.max(np.abs(y1 - ry) / (1 + np.abs(ry)))
+        regular = ref_stats[0, 1] <= 1           # the first FD Jacobian served the whole row
+        total += 1
+        loose += not regular
+        same += out["stats"][0, 0, :4].tolist() == ref_stats[0, :4].tolist()
+        assert err < (1e-7 if regular else 5e-3), (tag, name, err, out["stats"][0, 0], ref_stats)
+    print(f"[{tag}] {same}/{total} rows with the reference's nfev/njev/nlu/steps; {loose} in the refreshed-Jacobian tier")
+    assert total >= 6 and same >= total - 1, (same, total)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_two_days_at_the_point_match_the_oracle(gpu, tag):
+    """96 chained rows from the reference's spin-up state at the point, four members with their own noise."""
+    from oracle.oracle import Oracle
+    _, cols, forcing = digest_point(tag)
+    ic = golden(f"g1p_tables_{tag}.npz")["initial_cond"]
+    N, D, rows = 4, cols.dim_d, 96
+    rng = np.random.default_rng(31)
+    base = rng.standard_normal((N, D))
+    nf = int(forcing.refresh[1:1 + rows].sum())
+    fresh = rng.standard_normal((nf, N, D))
+    st = gpu.EnsembleStepper(cols, forcing, N)
+    st.set_state(ic)
+    st.set_noise_host(base)
+    out = st.step_rows(1, rows, fresh_noise=fresh, want_wtd=True, want_psi=True)
+    st.close()
+    o = Oracle(cols, forcing.surface_evap)
+    equal = total = 0
+    for k in range(N):
+        ref = o.run(forcing, ic, base[k], fresh[:, k, :], 1, 1 + rows, want_psi=True)
+        e = np.max(np.abs(out["psi"][:, k, :] - ref["psi_rows"][1:1 + rows]) / (1 + np.abs(ref["psi_rows"][1:1 + rows])),
+                   axis=1)
+        assert e[0] < 1e-9 and e.max() < 1e-3, (tag, k, e[0], e.max())
+        equal += int((out["wtd"][:, k] == ref["wtd_est"][1:1 + rows]).sum())
+        total += rows
+    assert equal >= 0.98 * total, (equal, total)
