@@ -17,8 +17,10 @@ moments over RCCL -- runs after the timed region and is reported separately.
 
 Prints ONE JSON line (rank 0).  roofline.achieved uses the algorithmic bytes of SURVEY.md §8d,
 (16*D + 16) B per column-step, over the step kernel's mean launch duration measured with HIP
-events on the library's stream.  cpu_baseline times the C oracle (oracle/, a port of the same
-algorithm) on the host cores over a bounded sample of the same workload.
+events on the library's stream.  Two more legs run AFTER the timed region on rank 0 of a one-GPU run:
+`sustained` -- 16 384 members through the first 365 days of the same forcing digest (what the stepper holds
+over a whole simulated year, with the failed-attempt / iteration-guard counters) -- and `cpu_baseline` -- the C oracle
+(oracle/, a port of the same algorithm) on every host core this process may use, for >= 30 s.
 """
 import argparse
 import json
@@ -58,34 +60,83 @@ def parse():
     ap.add_argument("--years", type=int, default=10)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="wall time of the CPU leg (BASELINE.md §3: >= 30 s)")
+    ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--sustained-members", type=int, default=16384)
+    ap.add_argument("--sustained-days", type=int, default=365)
     ap.add_argument("--ic-file", default="", help="npz cache of the spun-up initial condition (written if missing)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     return ap.parse_args()
 
 
-def cpu_baseline(cols, forcing, psi0, threads, rows, members_per_thread, seed=5):
-    """Oracle (CPU port) on `threads` host threads; returns column-days/s and what was run."""
+def host_cores():
+    """Cores this process may run on (the GPU box gives a one-GPU job a share of the host), and the host's total."""
+    total = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = total
+    return max(1, min(usable, total)), total
+
+
+def cpu_baseline(cols, forcing, psi0, threads, seconds, first_row=1 + ROWS_PER_DAY, days_per_member=10, seed=5):
+    """C oracle (CPU port of the same algorithm) on `threads` host threads for ~`seconds` of wall time: every thread
+    integrates members (own noise stream) through the same `days_per_member` days the GPU leg starts its timed region
+    on, one after another, until the deadline; only completed members count."""
     from oracle.oracle import Oracle, lib
     lib()
     D = cols.dim_d
-    n_ref = int(forcing.refresh[1:1 + rows].sum())
+    rows = days_per_member * ROWS_PER_DAY
+    n_ref = int(forcing.refresh[first_row:first_row + rows].sum())
+    deadline = time.perf_counter() + seconds
 
     def work(tid):
         orc = Oracle(cols, forcing.surface_evap)
         rng = np.random.default_rng(seed + tid)
-        for _ in range(members_per_thread):
-            orc.run(forcing, psi0, rng.standard_normal(D), rng.standard_normal((max(n_ref, 1), D)), 1, 1 + rows)
-        return members_per_thread
+        done = 0
+        while True:
+            orc.run(forcing, psi0, rng.standard_normal(D), rng.standard_normal((max(n_ref, 1), D)), first_row,
+                    first_row + rows)
+            done += 1
+            if time.perf_counter() >= deadline:
+                return done
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=threads) as ex:
         done = sum(ex.map(work, range(threads)))
     wall = time.perf_counter() - t0
-    days = done * rows / ROWS_PER_DAY
+    days = done * days_per_member
+    usable, total = host_cores()
     return {"value": days / wall, "unit": "column-days/s", "cores": threads, "kind": "port",
-            "sample": f"{done} members x {rows} rows (D={D}) of the same forcing, C oracle, "
-                      f"{threads} threads, {wall:.1f} s wall"}
+            "per_core": days / wall / threads, "host_cores_total": total, "host_cores_usable": usable,
+            "sample": f"{done} members x {rows} rows (days {(first_row - 1) // ROWS_PER_DAY + 1}.."
+                      f"{(first_row - 1) // ROWS_PER_DAY + days_per_member}, D={D}) of the same forcing, C oracle, "
+                      f"{threads} threads (all cores usable by this process), {wall:.1f} s wall"}
+
+
+def sustained_leg(cols, forcing, psi0, members, days, seed, device):
+    """What the stepper sustains over a whole simulated year: `members` members through the first `days` days of the
+    same digest, one 48-row launch per day, with the failed-attempt and iteration-guard counters of the run."""
+    from hydromodel_amd.ensemble import EnsembleSimulation
+    days = min(days, (forcing.dim_t - 1) // ROWS_PER_DAY)
+    sim = EnsembleSimulation(cols, forcing, members, seed=seed, device=device, psi0=psi0)
+    t0 = time.perf_counter()
+    for _ in range(days):
+        sim.advance(ROWS_PER_DAY)
+    wall = time.perf_counter() - t0
+    cnt = sim.stepper.counters()
+    mean_cm, std_cm = sim.wtd_mean_std()
+    last = sim.next_row - 1
+    out = {"value": members * days / wall, "unit": "column-days/s", "members": members, "days": days,
+           "wall_s": wall, "kernel_s": sim.kernel_ms * 1e-3, "launches": sim.launches,
+           "failed_attempts": cnt["failed_attempts"], "guard_trips": cnt["guard_trips"],
+           "failed_attempts_per_member_year": cnt["failed_attempts"] / members * 365.0 / days,
+           "wtd_mean_cm_last_row": float(mean_cm[last]), "wtd_std_cm_last_row": float(std_cm[last]),
+           "wtd_std_cm_max": float(np.nanmax(std_cm[1:last + 1])),
+           "workload": f"{members} members x D={cols.dim_d}, days 1..{days} of the same {forcing.dim_t}-row digest"}
+    sim.close()
+    return out
 
 
 def main():
@@ -207,13 +258,18 @@ def main():
         "wtd_mean_cm_last_row": float(mean_cm[last_row]), "wtd_std_cm_last_row": float(std_cm[last_row]),
         "spinup_iterations": spin_iters,
     }
+    sim.close()
+    if rank == 0 and world == 1 and not args.no_sustained:
+        out["sustained"] = sustained_leg(cols, forcing, psi0, args.sustained_members, args.sustained_days, args.seed,
+                                         local_rank)
+    elif rank == 0:
+        out["sustained"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-        out["cpu_baseline"] = cpu_baseline(cols, forcing, psi0, threads, rows=4 * ROWS_PER_DAY,
-                                           members_per_thread=32)
+        threads = args.cpu_threads or host_cores()[0]
+        out["cpu_baseline"] = cpu_baseline(cols, forcing, psi0, threads, args.cpu_seconds,
+                                           first_row=1 + args.warmup * ROWS_PER_DAY)
     elif rank == 0:
         out["cpu_baseline"] = None
-    sim.close()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -27,7 +27,8 @@ class ColumnParams(C.Structure):
                                           "n_root_first", "n_root_int", "n_groups")] +
                 [(k, C.c_double) for k in ("theta_res", "alpha", "n", "m", "psi_sat", "epsilon",
                                            "lambda_exp", "sigma_noise", "sat_soil", "dz", "ipsi50", "lai",
-                                           "surface_evap", "interception", "evap_delta_min")])
+                                           "surface_evap", "interception", "evap_delta_min")] +
+                [("flag_predict", C.c_int32), ("sat_cells", C.c_int32)])
 
 
 class StepArgs(C.Structure):
@@ -50,6 +51,8 @@ EXPORTS = {
     "hc_last_error": ([], C.c_char_p),
     "hc_version": ([], C.c_char_p),
     "hc_set_column": ([C.c_void_p, C.POINTER(ColumnParams), _dp, _dp, _ip], C.c_int),
+    "hc_add_point": ([C.c_void_p, C.POINTER(ColumnParams), _dp, _dp], C.c_int),
+    "hc_get_point_count": ([C.c_void_p], C.c_int),
     "hc_set_forcing": ([C.c_void_p, C.c_int64, _dp, _dp, _bp, _ip, _bp], C.c_int),
     "hc_set_members": ([C.c_void_p, C.c_int64], C.c_int),
     "hc_set_state": ([C.c_void_p, _dp, C.c_int], C.c_int),
@@ -62,11 +65,14 @@ EXPORTS = {
     "hc_spinup": ([C.c_void_p, C.POINTER(SpinupArgs)], C.c_int),
     "hc_synchronize": ([C.c_void_p], C.c_int),
     "hc_get_counters": ([C.c_void_p, C.POINTER(C.c_uint64)], C.c_int),
+    "hc_set_iteration_budget": ([C.c_void_p, C.c_int32], C.c_int),
     "hc_get_moments": ([C.c_void_p, _lp], C.c_int),
     "hc_set_moments": ([C.c_void_p, _lp], C.c_int),
     "hc_reset_moments": ([C.c_void_p], C.c_int),
     "hc_rhs": ([C.c_void_p, C.c_int64, C.c_int32, _dp, _dp], C.c_int),
     "hc_model_nodes": ([C.c_void_p, _dp, _dp], C.c_int),
+    "hc_plugin_eval": ([C.c_int, C.POINTER(ColumnParams), C.c_int64, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+                       C.c_int),
 }
 
 _lib = None

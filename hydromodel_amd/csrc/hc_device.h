@@ -32,12 +32,17 @@ struct ColumnDev {
     double mn_alpha;    // (m*n)*alpha
     double inv_m;       // 1/m
     double por_node0;   // porosity the top-node BC call sees
+    // repaired PREDICT mode (richards_pde.py:312-351; an extension, the reference raises TypeError at :327-330):
+    // low_lim = dim_d - (sat_cells - 1) of the interior call (k = D - 2 cells) as an int, 0 when not positive;
+    // predict_first = 1 when the single-cell first-midpoint call has low_lim >= 1 (sat_cells <= 1)
+    int flag_predict, predict_low, predict_first, pad_;
 };
 
 struct RowDev {
     double precip, atm;
     int daylight, wtd_obs, spinup;
     int diag;   // also integrate transpiration / lateral flow of the interior call (pde_model.arg_out)
+    int wet;    // PREDICT mode: month in {10, 11, 12, 1, 2, 3} (richards_pde.py:315)
 };
 
 // ---------------------------------------------------------------- wave primitives
@@ -854,7 +859,37 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         int wtd_est = jstar < 0 ? 0 : jstar;                  // p* + 1
         wtd_est = wtd_est < k - 1 ? wtd_est : k - 1;
         const int wtd_obs = R.wtd_obs < k - 1 ? R.wtd_obs : k - 1;
-        if (wtd_est < wtd_obs) {
+        if (P.flag_predict) {
+            // Predictive mode, richards_pde.py:312-351 with `low_lim` as an int (clamped at 0): ONE cell, the
+            // estimated water table itself, drains with alpha_low (1 - (j / low_lim) ** nu[j]),
+            // nu = linspace(1.5, 0, low_lim).  All of it is wave-uniform scalar work.
+            const double alpha_low = R.wet ? -2.5e-3 : -1.5e-3;
+            if (wtd_est < P.predict_low) {
+                double pw = 0.0;                                      // 0 ** 1.5
+                if (wtd_est > 0) {
+                    double nu;
+                    {
+#pragma clang fp contract(off)
+                        const double step = -1.5 / (double)(P.predict_low - 1);   // numpy linspace: delta / (num - 1)
+                        nu = (double)wtd_est * step + 1.5;
+                    }
+                    nu = wtd_est == P.predict_low - 1 ? 0.0 : nu;     // linspace pins the last sample to `stop`
+                    pw = exp_mid(nu * log_pos((double)wtd_est / (double)P.predict_low));
+                }
+                const double alpha_lat = alpha_low * (1.0 - pw);
+                double s_l = 0.0;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    const int p = lane * CPL + c - 1;
+                    const bool in = p == wtd_est;
+                    sk[c] = in ? fmin(alpha_lat * ym[c], sk[c]) : sk[c];
+                    s_l += in ? fabs(sk[c]) : 0.0;
+                }
+                if (R.diag) diag_lf = wave_sum(s_l) * P.dz;
+            }
+            if (P.predict_first)   // single-cell call: wtd_est = 0 < low_lim, alpha_lat = alpha_low (1 - 0 ** 1.5)
+                sk[0] = lane == 0 ? fmin(alpha_low * ym[0], sk[0]) : sk[0];
+        } else if (wtd_est < wtd_obs) {
             double s_l = 0.0;
 #pragma unroll
             for (int c = 0; c < CPL; c++) {

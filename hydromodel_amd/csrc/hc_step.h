@@ -77,9 +77,9 @@ constexpr unsigned PHILOX_DRAW_SPINUP = 0xFFFFFFFFu;
 constexpr int HC_TRACE_N = 20000;
 
 struct StepArgs {
-    const ColumnDev *P;       // device memory
+    const ColumnDev *P;       // device memory, [n_points]
     const IoArgs *io;         // device memory
-    const double *tab;        // [NTAB][SLOTS]
+    const double *tab;        // [n_points][NTAB][SLOTS]
     const int *gtab;          // [NGTAB][SLOTS]
     long long n_members;
     int n_rows, spinup, D, n_groups, host_noise;
@@ -89,6 +89,12 @@ struct StepArgs {
     int spin_stop;
     double spin_zwtd, spin_z0, spin_dz;
     int max_phase_iterations; // MAX_PHASE_ITERATIONS (test hook: HYDROCOL_DEBUG_MAX_ITER lowers it to force abandoned attempts)
+    // parameter points (BASELINE config 5): P[n_points], tab[n_points][NTAB][SLOTS]; members are point-major, point k owns
+    // members [k * members_per_point, (k + 1) * members_per_point).  With more than one point a workgroup works through
+    // chunks of `chunk_members` members of ONE point (its tables sit in LDS); chunk c = (point c / chunks_per_point,
+    // members (c % chunks_per_point) * chunk_members ... of that point).
+    int n_points, chunk_members, chunks_per_point, n_chunks;
+    long long members_per_point;
 };
 
 // Uniform struct load from device memory through the constant address space (s_load_dwordxN).  The empty
@@ -418,8 +424,19 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     double *wave_base = reinterpret_cast<double *>(gtab + 4 * SLOTS);
     constexpr bool NZ_LDS = nz_in_lds(CPL);
     constexpr int NVEC_K = nvec_of(CPL);
-    for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
+    // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
+    // [0] next member of the chunk, [1] its end (-1: no chunk left), [2] point whose tables are in LDS, [3] the chunk's point
+    volatile int *chunk_state = reinterpret_cast<volatile int *>(gtab + NGTAB * SLOTS);
+    const bool multi = A.n_points > 1;
+    if (!multi)
+        for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
     for (int k = threadIdx.x; k < NGTAB * SLOTS; k += WPB * WAVE) gtab[k] = (signed char)A.gtab[k];
+    if (threadIdx.x == 0) {
+        chunk_state[0] = 0;
+        chunk_state[1] = 0;
+        chunk_state[2] = -1;
+        chunk_state[3] = 0;
+    }
     __syncthreads();
 
     // No barrier below this line: every wave is an independent worker.  The grid is persistent (one
@@ -442,14 +459,66 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
 
     for (;;) {
     long long member;
-    {
+    int point = 0;
+    if (!multi) {
         const IoArgs io = load_const(A.io);
         unsigned long long ticket = 0;
         if (lane == 0) ticket = atomicAdd(io.queue, 1ull);
         member = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ticket >> 32)) << 32) |
                              (unsigned)__builtin_amdgcn_readfirstlane((int)ticket));
+        if (member >= A.n_members) break;
+    } else {
+        // Several parameter points: the four waves draw members of the workgroup's current chunk from an LDS counter.
+        // A wave that finds the chunk empty waits for the other three (the only barriers of the kernel), then one
+        // thread takes the next chunk from the device-wide ticket and, when its point differs from the one whose
+        // tables are in LDS, the workgroup reloads them.  Exit: no chunk left, seen by all four waves together.
+        bool none_left = false;
+        for (;;) {
+            int m = 0;
+            if (lane == 0) m = __hip_atomic_fetch_add(const_cast<int *>(chunk_state), 1, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            m = __builtin_amdgcn_readfirstlane(m);
+            // (LDS reads are per-lane values to the compiler: readfirstlane keeps the control flow scalar)
+            if (m < __builtin_amdgcn_readfirstlane(chunk_state[1])) {
+                member = m;
+                point = __builtin_amdgcn_readfirstlane(chunk_state[3]);
+                break;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const IoArgs io = load_const(A.io);
+                const unsigned long long c = atomicAdd(io.queue, 1ull);
+                if (c < (unsigned long long)A.n_chunks) {
+                    const int pt = (int)(c / (unsigned)A.chunks_per_point);
+                    const long long first = (long long)pt * A.members_per_point +
+                                            (long long)(c % (unsigned)A.chunks_per_point) * A.chunk_members;
+                    const long long last = (long long)(pt + 1) * A.members_per_point;
+                    chunk_state[3] = pt;
+                    chunk_state[0] = (int)first;
+                    chunk_state[1] = (int)(first + A.chunk_members < last ? first + A.chunk_members : last);
+                } else {
+                    chunk_state[0] = 0;
+                    chunk_state[1] = -1;
+                }
+            }
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(chunk_state[1]) < 0) {
+                none_left = true;
+                break;
+            }
+            const int pt = __builtin_amdgcn_readfirstlane(chunk_state[3]);
+            if (pt != __builtin_amdgcn_readfirstlane(chunk_state[2])) {
+                const double *src = A.tab + (size_t)pt * (NTAB * SLOTS);
+                for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = src[k];
+                __syncthreads();
+                if (threadIdx.x == 0) chunk_state[2] = pt;   // next read: after the first barrier of the next chunk change
+            }
+        }
+        if (none_left) break;
     }
-    if (member >= A.n_members) break;
+    point = __builtin_amdgcn_readfirstlane(point);
+    double psi_sat_m = A.psi_sat;
+    if (multi) psi_sat_m = load_const(A.P + point).psi_sat;
     bool vnode[CPL];
     int gs[CPL], gp[CPL], gn[CPL];
 #pragma unroll
@@ -480,7 +549,9 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
             row = A.spinup ? io.row_begin : io.row_begin + r;
             R.precip = io.precip[row];
             R.atm = io.atm[row];
-            R.daylight = io.daylight[row];
+            const int day_bits = io.daylight[row];   // bit 0: daylight, bit 1: wet season (PREDICT mode)
+            R.daylight = day_bits & 1;
+            R.wet = (day_bits >> 1) & 1;
             R.wtd_obs = io.wtd_obs[row];
             R.spinup = A.spinup;
             R.diag = io.diag != nullptr;
@@ -489,7 +560,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         double diag_tr = 0.0, diag_lf = 0.0, spin_mse = INFINITY;
         const double t0 = A.spinup ? 0.0 : (double)(row - 1);
         const double tf = t0 + 1.0;
-        int st_nfev = 0, st_njev = 0, st_nlu = 0, st_nsteps = 0, attempts = 0;
+        int st_nfev = 0, st_njev = 0, st_nlu = 0, st_nsteps = 0, attempts = 0, failed_row = 0;
         bool skip = (R.wtd_obs < 0) && !A.spinup;    // simulation.py:582-588
         if (!skip) {
             // ---- noise vector of this row -> V_NZ (simulation.py:592,599-602)
@@ -579,7 +650,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 int phase = PH_F0;
                 // column parameters: one scalar-memory read per attempt.  (Per RHS evaluation the lone wave sat out
                 // the load latency 24 times per row; for the kernel's lifetime they cost ~60 SGPRs, see DESIGN.md.)
-                const ColumnDev P = load_const(A.P);
+                const ColumnDev P = load_const(A.P + point);
                 int guard = 0;                       // every wave must reach an exit: bound the phase loop
 #ifdef HC_PROFILE
                 unsigned long long prof_t = clock64();
@@ -1106,6 +1177,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 }
                 spin_mse = wave_sum(sq) / (double)D;
             }
+            failed_row = failed;
             if (failed) {
                 nz_is_base = false;
                 const IoArgs io = load_const(A.io);
@@ -1134,7 +1206,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
             yv[c] = V[V_Y * SLOTS + c * WAVE + lane];
-            unsat[c] = vnode[c] && !(yv[c] >= A.psi_sat);
+            unsat[c] = vnode[c] && !(yv[c] >= psi_sat_m);
         }
         const int istar = deepest_true<CPL>(unsat);
         int w = istar < 0 ? 0 : istar + 1;
@@ -1155,7 +1227,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 io.wtd_u16[(size_t)r * A.n_members + member] = (unsigned short)w;
                 if (io.stats) {
                     int *s = io.stats + ((size_t)r * A.n_members + member) * 6;
-                    s[0] = st_nfev; s[1] = st_njev; s[2] = st_nlu; s[3] = st_nsteps; s[4] = attempts; s[5] = refresh;
+                    s[0] = st_nfev; s[1] = st_njev; s[2] = st_nlu; s[3] = st_nsteps; s[4] = attempts; s[5] = (int)refresh | (failed_row << 8);
                 }
             }
             if (io.psi_rows) {

@@ -17,6 +17,11 @@
 
 using namespace hc;
 
+// layouts the ctypes binding (hydromodel_amd/_lib.py) mirrors; tests/test_abi.py checks the Python side
+static_assert(sizeof(hc_column_params) == 8 * 4 + 15 * 8 + 2 * 4, "hc_column_params layout");
+static_assert(sizeof(hc_step_args) == 8 + 8 + 4 + 4 + 5 * 8 + 8 + 8, "hc_step_args layout");
+static_assert(sizeof(hc_spinup_args) == 8 + 4 + 4 + 8 + 8 + 8 + 8, "hc_spinup_args layout");
+
 namespace {
 
 thread_local std::string g_err;
@@ -70,10 +75,16 @@ struct hc_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_column = false, have_forcing = false, have_noise = false;
-    hc_column_params p{};
-    ColumnDev P{};
+    hc_column_params p{};        // parameter point 0; dim_d, n_groups and dz are shared by every point
+    ColumnDev P{};               // point 0
     int cpl = 0, wpb = 0, slots = 0;
-    bool special = false;
+    bool special = false;        // every point is vrettas_fung with n = 2, m = 1/2, lambda = 1
+    // parameter points (BASELINE config 5): host copies, uploaded by fill_args when `points_dirty`
+    int n_points = 0, moments_points = 0;
+    std::vector<ColumnDev> P_host;
+    std::vector<double> tab_host, node_host;
+    bool points_dirty = false;
+    int chunk_members = 0;       // HYDROCOL_CHUNK_MEMBERS (0: derived from the member count)
     DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
     DevBuf<int> spin_iters;
     DevBuf<double> trace;        // diagnostic builds only
@@ -101,13 +112,17 @@ struct hc_handle {
 namespace hc {
 
 // per-row ensemble moments of the water-table index: one block per row, single writer
+// (blockIdx.y = parameter point: its members are contiguous, its table is moments[point][3][n_forcing])
 __global__ void moments_kernel(const unsigned short *wtd, const int *wtd_obs, long long n_members,
-                               long long row_begin, int spinup, long long n_forcing, long long *moments)
+                               long long members_per_point, long long row_begin, long long n_forcing,
+                               long long *moments_all)
 {
     const int r = blockIdx.x;
-    const long long row = spinup ? row_begin : row_begin + r;
+    const long long row = row_begin + r;
+    const long long first = (long long)blockIdx.y * members_per_point;
+    long long *moments = moments_all + (size_t)blockIdx.y * 3 * n_forcing;
     long long s1 = 0, s2 = 0;
-    for (long long k = threadIdx.x; k < n_members; k += blockDim.x) {
+    for (long long k = first + threadIdx.x; k < first + members_per_point; k += blockDim.x) {
         const long long w = wtd[(size_t)r * n_members + k];
         s1 += w;
         s2 += w * w;
@@ -124,7 +139,7 @@ __global__ void moments_kernel(const unsigned short *wtd, const int *wtd_obs, lo
         __syncthreads();
     }
     if (threadIdx.x == 0 && wtd_obs[row] >= 0) {
-        moments[row] += n_members;
+        moments[row] += members_per_point;
         moments[n_forcing + row] += sh1[0];
         moments[2 * n_forcing + row] += sh2[0];
     }
@@ -142,10 +157,11 @@ __global__ void fill_d(double *p, double v, size_t n)
     if (k < n) p[k] = v;
 }
 
-__global__ void broadcast_state(const double *src, double *dst, int D, long long n_members)
+// src holds one column per parameter point ([n_points][D]; one point: a single column for everybody)
+__global__ void broadcast_state(const double *src, double *dst, int D, long long n_members, long long members_per_point)
 {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < (size_t)D * n_members) dst[k] = src[k % D];
+    if (k < (size_t)D * n_members) dst[k] = src[((k / D) / members_per_point) * D + k % D];
 }
 
 __global__ void philox_dump(unsigned long long seed, long long member, unsigned draw, int D, double *out)
@@ -175,7 +191,8 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
     RowDev R;
     R.precip = io.precip[row];
     R.atm = io.atm[row];
-    R.daylight = io.daylight[row];
+    R.daylight = io.daylight[row] & 1;
+    R.wet = (io.daylight[row] >> 1) & 1;
     R.wtd_obs = io.wtd_obs[row];
     R.spinup = A.spinup;
     R.diag = 0;
@@ -223,14 +240,16 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
 __global__ void model_nodes_kernel(const StepArgs A, const double *node_tabs, int special, double *out,
                                    double *qinf)
 {
-    const ColumnDev P = load_const(A.P);
     const IoArgs io = load_const(A.io);
-    const int D = P.D;
+    const int D = A.D;
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)A.n_members * D;
     if (k >= total) return;
     const long long member = k / D;
     const int i = (int)(k % D);
+    const long long point = member / A.members_per_point;
+    const ColumnDev P = A.P[point];
+    node_tabs += (size_t)point * 3 * D;
     const double por = node_tabs[i], meank = node_tabs[D + i], noisec = node_tabs[2 * D + i];
     const double mk = meank == 0.0 ? 1.0e-7 : meank;
     double z;
@@ -248,6 +267,30 @@ __global__ void model_nodes_kernel(const StepArgs A, const double *node_tabs, in
     out[2 * total + k] = C;
     out[3 * total + k] = kb;
     if (qinf && i == 0) qinf[member] = fmin(2.0 * (por - th) * P.dz, kb);
+}
+
+// Stateless plugin call on arbitrary depths: psi [n_cells][n_cols] (depth-major, the reference's [dim_d x dim_m]),
+// per-cell tables and noise [n_cells]; out [4][n_cells][n_cols] = theta, K, C, K_bkg; qinf [n_cols] from row 0
+// (vrettas_fung.py:51-257, vanGenuchten.py:23-126).
+__global__ void plugin_kernel(const ColumnDev P, int special, long long n_cells, long long n_cols, const double *psi,
+                              const double *por, const double *meank, const double *noisec, const double *n_rnd,
+                              double *out, double *qinf)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_cells * n_cols;
+    if (k >= total) return;
+    const long long i = k / n_cols;
+    const double mk = meank[i] == 0.0 ? 1.0e-7 : meank[i];
+    double th, K, C, kb, pf;
+    if (special)
+        model_cell<true>(P, psi[k], por[i], 0.0, log(mk), 1.0 / (mk * mk), noisec[i], noisec[i] * n_rnd[i], th, K, C, kb, pf);
+    else
+        model_cell<false>(P, psi[k], por[i], 0.0, log(mk), 1.0 / (mk * mk), noisec[i], noisec[i] * n_rnd[i], th, K, C, kb, pf);
+    out[k] = th;
+    out[total + k] = K;
+    out[2 * total + k] = C;
+    out[3 * total + k] = kb;
+    if (i == 0) qinf[k] = fmin(2.0 * (por[0] - th) * P.dz, kb);
 }
 
 }  // namespace hc
@@ -345,7 +388,35 @@ int fill_args(hc_handle *h, StepArgs &A)
     memset(&A, 0, sizeof(A));
     IoArgs &io = h->io_host;
     memset(&io, 0, sizeof(io));
-    if (h->Pdev.ensure(1) || h->iodev.ensure(1)) return HC_ERR_DEVICE;
+    const int NP = h->n_points;
+    if (h->n_members % NP != 0)
+        return fail(HC_ERR_ARG, "%lld members do not divide into %d parameter points", (long long)h->n_members, NP);
+    if (h->Pdev.ensure((size_t)NP) || h->iodev.ensure(1)) return HC_ERR_DEVICE;
+    if (h->points_dirty) {
+        if (h->tab.ensure(h->tab_host.size()) || h->node_tabs.ensure(h->node_host.size())) return HC_ERR_DEVICE;
+        HIP_TRY(hipMemcpy(h->tab.p, h->tab_host.data(), h->tab_host.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->node_tabs.p, h->node_host.data(), h->node_host.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->Pdev.p, h->P_host.data(), (size_t)NP * sizeof(ColumnDev), hipMemcpyHostToDevice));
+        h->points_dirty = false;
+    }
+    if (h->moments_points != NP) {      // one [3][T] table per point, zeroed when the number of points changes
+        const size_t cnt = (size_t)NP * 3 * h->n_rows;
+        if (h->moments.ensure(cnt)) return HC_ERR_DEVICE;
+        HIP_TRY(hipMemset(h->moments.p, 0, cnt * 8));
+        h->moments_points = NP;
+    }
+    A.n_points = NP;
+    A.members_per_point = h->n_members / NP;
+    {
+        // chunks of one point's members for the multi-point scheduler: >= 8 chunks per workgroup when the ensemble
+        // allows it, <= 128 members each (32 per wave bound the idle time at a chunk's end to ~1.5 %)
+        long long chunk = h->chunk_members > 0 ? h->chunk_members : (h->n_members + 8LL * h->n_cu - 1) / (8LL * h->n_cu);
+        chunk = std::max<long long>(4, std::min<long long>(chunk, 128));
+        chunk = std::min<long long>(chunk, A.members_per_point);
+        A.chunk_members = (int)chunk;
+        A.chunks_per_point = (int)((A.members_per_point + chunk - 1) / chunk);
+        A.n_chunks = A.chunks_per_point * NP;
+    }
     A.P = h->Pdev.p;
     A.io = h->iodev.p;
     A.tab = h->tab.p;
@@ -402,16 +473,26 @@ int hc_create(int device_ordinal, hc_handle **out)
     HIP_TRY(hipSetDevice(device_ordinal));
     hc_handle *h = new hc_handle();
     h->device = device_ordinal;
-    HIP_TRY(hipStreamCreate(&h->stream));
-    HIP_TRY(hipEventCreate(&h->ev0));
-    HIP_TRY(hipEventCreate(&h->ev1));
-    if (h->counters.ensure(64) != HC_OK) return HC_ERR_DEVICE;
-    HIP_TRY(hipMemset(h->counters.p, 0, 64 * sizeof(unsigned long long)));
-    {
+    // everything acquired so far is released when a later step fails
+    auto init = [&]() -> int {
+        HIP_TRY(hipStreamCreate(&h->stream));
+        HIP_TRY(hipEventCreate(&h->ev0));
+        HIP_TRY(hipEventCreate(&h->ev1));
+        if (h->counters.ensure(64) != HC_OK) return HC_ERR_DEVICE;
+        HIP_TRY(hipMemset(h->counters.p, 0, 64 * sizeof(unsigned long long)));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
         h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        return HC_OK;
+    };
+    if (const int rc = init()) {
+        const std::string keep = g_err;
+        hc_destroy(h);
+        g_err = keep;
+        return rc;
     }
+    if (const char *cm = getenv("HYDROCOL_CHUNK_MEMBERS"))
+        if (atoi(cm) > 0) h->chunk_members = atoi(cm);
     const char *rpl = getenv("HYDROCOL_ROWS_PER_LAUNCH");
     if (rpl && atoi(rpl) > 0) h->rows_per_launch = atoi(rpl);
     if (const char *sg = getenv("HYDROCOL_STRICT_GUARD")) h->strict_guard = atoi(sg) != 0;
@@ -443,27 +524,18 @@ int hc_destroy(hc_handle *h)
     return HC_OK;
 }
 
-int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_tabs, const double *mid_tabs,
-                  const int32_t *groups)
+// One parameter point: ColumnDev + the slot tables of the stepper.  `first` fixes the geometry shared by all points.
+static int build_point(hc_handle *h, const hc_column_params *p, const double *node_tabs, const double *mid_tabs,
+                       bool first)
 {
-    if (!h || !p || !node_tabs || !mid_tabs || !groups) return fail(HC_ERR_ARG, "hc_set_column: NULL argument");
     const int D = p->dim_d;
-    if (D < 4 || D > HC_MAX_DEPTH_NODES) return fail(HC_ERR_ARG, "dim_d = %d outside [4, %d]", D, HC_MAX_DEPTH_NODES);
-    if (p->n_groups < 1 || p->n_groups > 16) return fail(HC_ERR_ARG, "n_groups = %d outside [1,16]", p->n_groups);
     if (!(p->dz > 0.0) || !(p->n > 1.0) || !(p->alpha > 0.0)) return fail(HC_ERR_ARG, "bad dz / n / alpha");
     if (p->n_root_first < 0 || p->n_root_first > 1 || p->n_root_int < 0 || p->n_root_int > D - 2)
         return fail(HC_ERR_ARG, "bad root-zone cell counts");
-    for (int i = 0; i < D; i++)
-        if (groups[i] < 0 || groups[i] >= p->n_groups) return fail(HC_ERR_ARG, "groups[%d] out of range", i);
-    HIP_TRY(hipSetDevice(h->device));
-    h->p = *p;
-    int cpl = (D + WAVE - 1) / WAVE;
-    if (cpl < 2) cpl = 2;
-    h->cpl = cpl;
-    h->wpb = 4;
-    h->slots = WAVE * cpl;
-    h->special = (p->model == HC_MODEL_VRETTAS_FUNG && p->n == 2.0 && p->m == 0.5 && p->lambda_exp == 1.0);
-    ColumnDev &P = h->P;
+    if (!first && (D != h->p.dim_d || p->n_groups != h->p.n_groups || p->dz != h->p.dz))
+        return fail(HC_ERR_ARG, "a parameter point must share dim_d, n_groups and dz with point 0");
+    if (p->flag_predict && p->sat_cells < 0) return fail(HC_ERR_ARG, "PREDICT mode: sat_cells < 0");
+    ColumnDev P{};
     P.D = D; P.model = p->model; P.flag_et = p->flag_et; P.flag_lf = p->flag_lf; P.flag_hlift = p->flag_hlift;
     P.n_root_first = p->n_root_first; P.n_root_int = p->n_root_int; P.n_groups = p->n_groups;
     P.theta_res = p->theta_res; P.alpha = p->alpha; P.n = p->n; P.m = p->m; P.psi_sat = p->psi_sat;
@@ -473,10 +545,14 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
     P.mn_alpha = (p->m * p->n) * p->alpha;
     P.inv_m = 1.0 / p->m;
     P.por_node0 = node_tabs[0];
+    // repaired PREDICT mode: low_lim = dim_d - (sat_cells - 1) of each pde_fun call as an int, nothing drains when
+    // it is not positive (the reference's np.linspace(1.5, 0.0, low_lim) raises for a float or a negative count)
+    P.flag_predict = p->flag_predict ? 1 : 0;
+    P.predict_low = std::max(0, (D - 2) - (p->sat_cells - 1));
+    P.predict_first = (1 - (p->sat_cells - 1)) >= 1 ? 1 : 0;
 
-    const int M = D - 1, S = h->slots;
+    const int M = D - 1, S = h->slots, cpl = h->cpl;
     std::vector<double> tab((size_t)NTAB * S);
-    std::vector<int> gt((size_t)NGTAB * S, -1);
     auto put = [&](int slot, double por, double fc, double wlt, double root, double meank, double noisec) {
         const double mk = meank == 0.0 ? 1.0e-7 : meank;   // utilities.py:50
         tab[(size_t)T_POR * S + slot] = por;
@@ -499,24 +575,76 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
             else
                 put(slot, 0.3, 0.2, 0.1, 0.0, 1.0, 0.0);    // padding cell: benign, results masked
             if (i >= M) tab[(size_t)T_VALID * S + slot] = 0.0;
+        }
+    // virtual top-node cell in the always-free slot (lane 63, c = cpl-1)
+    put((cpl - 1) * WAVE + (WAVE - 1), node_tabs[0], 0.2, 0.1, 0.0, node_tabs[D + 0], node_tabs[2 * D + 0]);
+    tab[(size_t)T_VALID * S + (cpl - 1) * WAVE + (WAVE - 1)] = 0.0;   // its C / flux never enter the assembly
+    for (double v : tab)
+        if (!std::isfinite(v)) return fail(HC_ERR_ARG, "a column table entry is not finite");
+    const bool special = (p->model == HC_MODEL_VRETTAS_FUNG && p->n == 2.0 && p->m == 0.5 && p->lambda_exp == 1.0);
+    if (first) {
+        h->P_host.clear(); h->tab_host.clear(); h->node_host.clear();
+        h->n_points = 0;
+        h->p = *p;
+        h->P = P;
+        h->special = special;
+    } else {
+        h->special = h->special && special;
+    }
+    h->P_host.push_back(P);
+    h->tab_host.insert(h->tab_host.end(), tab.begin(), tab.end());
+    h->node_host.insert(h->node_host.end(), node_tabs, node_tabs + (size_t)3 * D);
+    h->n_points++;
+    h->points_dirty = true;
+    return HC_OK;
+}
+
+int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_tabs, const double *mid_tabs,
+                  const int32_t *groups)
+{
+    if (!h || !p || !node_tabs || !mid_tabs || !groups) return fail(HC_ERR_ARG, "hc_set_column: NULL argument");
+    const int D = p->dim_d;
+    if (D < 4 || D > HC_MAX_DEPTH_NODES) return fail(HC_ERR_ARG, "dim_d = %d outside [4, %d]", D, HC_MAX_DEPTH_NODES);
+    if (p->n_groups < 1 || p->n_groups > 16) return fail(HC_ERR_ARG, "n_groups = %d outside [1,16]", p->n_groups);
+    for (int i = 0; i < D; i++)
+        if (groups[i] < 0 || groups[i] >= p->n_groups) return fail(HC_ERR_ARG, "groups[%d] out of range", i);
+    HIP_TRY(hipSetDevice(h->device));
+    int cpl = (D + WAVE - 1) / WAVE;
+    if (cpl < 2) cpl = 2;
+    h->cpl = cpl;
+    h->wpb = 4;
+    h->slots = WAVE * cpl;
+    h->have_column = false;
+    int rc = build_point(h, p, node_tabs, mid_tabs, true);
+    if (rc) return rc;
+    const int S = h->slots;
+    std::vector<int> gt((size_t)NGTAB * S, -1);
+    for (int lane = 0; lane < WAVE; lane++)
+        for (int c = 0; c < cpl; c++) {
+            const int i = lane * cpl + c, slot = c * WAVE + lane;
             if (i < D) {
                 gt[(size_t)G_SELF * S + slot] = groups[i];
                 gt[(size_t)G_PREV * S + slot] = i >= 1 ? groups[i - 1] : -1;
                 gt[(size_t)G_NEXT * S + slot] = i < D - 1 ? groups[i + 1] : -1;
             }
         }
-    // virtual top-node cell in the always-free slot (lane 63, c = cpl-1)
-    put((cpl - 1) * WAVE + (WAVE - 1), node_tabs[0], 0.2, 0.1, 0.0, node_tabs[D + 0], node_tabs[2 * D + 0]);
-    tab[(size_t)T_VALID * S + (cpl - 1) * WAVE + (WAVE - 1)] = 0.0;   // its C / flux never enter the assembly
-    if (h->tab.ensure(tab.size()) || h->gtab.ensure(gt.size()) || h->node_tabs.ensure((size_t)3 * D))
-        return HC_ERR_DEVICE;
-    HIP_TRY(hipMemcpy(h->tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    if (h->gtab.ensure(gt.size())) return HC_ERR_DEVICE;
     HIP_TRY(hipMemcpy(h->gtab.p, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->node_tabs.p, node_tabs, (size_t)3 * D * 8, hipMemcpyHostToDevice));
-    if (h->Pdev.ensure(1)) return HC_ERR_DEVICE;
-    HIP_TRY(hipMemcpy(h->Pdev.p, &h->P, sizeof(ColumnDev), hipMemcpyHostToDevice));
     h->have_column = true;
     return HC_OK;
+}
+
+int hc_add_point(hc_handle *h, const hc_column_params *p, const double *node_tabs, const double *mid_tabs)
+{
+    if (!h || !p || !node_tabs || !mid_tabs) return fail(HC_ERR_ARG, "hc_add_point: NULL argument");
+    if (!h->have_column) return fail(HC_ERR_ARG, "hc_set_column (point 0) must come first");
+    return build_point(h, p, node_tabs, mid_tabs, false);
+}
+
+int hc_get_point_count(hc_handle *h)
+{
+    if (!h) return fail(HC_ERR_ARG, "NULL handle");
+    return h->n_points;
 }
 
 int hc_set_forcing(hc_handle *h, int64_t n_rows, const double *precip, const double *atm,
@@ -526,6 +654,12 @@ int hc_set_forcing(hc_handle *h, int64_t n_rows, const double *precip, const dou
         return fail(HC_ERR_ARG, "hc_set_forcing: bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const size_t T = (size_t)n_rows;
+    // A skipped row (wtd_obs < 0) consumes no noise draw: the reference `continue`s before drawing
+    // (simulation.py:582-588 come before :599-602), so its refresh flag is dropped here for everybody downstream.
+    std::vector<unsigned char> refresh_eff(refresh, refresh + T);
+    for (size_t i = 0; i < T; i++)
+        if (wtd_obs[i] < 0) refresh_eff[i] = 0;
+    refresh = refresh_eff.data();
     std::vector<int> draw(T, 0);
     int cnt = 0;
     for (size_t i = 0; i < T; i++) {
@@ -533,7 +667,7 @@ int hc_set_forcing(hc_handle *h, int64_t n_rows, const double *precip, const dou
         draw[i] = cnt;
     }
     if (h->precip.ensure(T) || h->atm.ensure(T) || h->daylight.ensure(T) || h->refresh.ensure(T) ||
-        h->wtd_obs.ensure(T) || h->draw_idx.ensure(T) || h->moments.ensure(3 * T))
+        h->wtd_obs.ensure(T) || h->draw_idx.ensure(T))
         return HC_ERR_DEVICE;
     HIP_TRY(hipMemcpy(h->precip.p, precip, T * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->atm.p, atm, T * 8, hipMemcpyHostToDevice));
@@ -541,9 +675,9 @@ int hc_set_forcing(hc_handle *h, int64_t n_rows, const double *precip, const dou
     HIP_TRY(hipMemcpy(h->refresh.p, refresh, T, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->wtd_obs.p, wtd_obs, T * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->draw_idx.p, draw.data(), T * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(h->moments.p, 0, 3 * T * 8));
     h->h_refresh.assign(refresh, refresh + T);
     h->n_rows = n_rows;
+    h->moments_points = 0;       // (re)allocated and zeroed by the next call that needs the moment tables
     h->have_forcing = true;
     return HC_OK;
 }
@@ -569,14 +703,19 @@ int hc_set_state(hc_handle *h, const double *psi, int broadcast)
     if (h->n_members <= 0) return fail(HC_ERR_ARG, "hc_set_members must come first");
     HIP_TRY(hipSetDevice(h->device));
     const int D = h->p.dim_d;
-    for (int i = 0; i < D; i++)
-        if (!std::isfinite(psi[i])) return fail(HC_ERR_ARG, "state entry %d is not finite", i);
+    if (broadcast < 0 || broadcast > 2) return fail(HC_ERR_ARG, "hc_set_state: broadcast must be 0, 1 or 2");
+    if (broadcast == 2 && h->n_members % h->n_points != 0)
+        return fail(HC_ERR_ARG, "%lld members do not divide into %d parameter points", (long long)h->n_members, h->n_points);
     const size_t n = (size_t)h->n_members * D;
+    const size_t n_in = broadcast == 1 ? (size_t)D : (broadcast == 2 ? (size_t)h->n_points * D : n);
+    for (size_t i = 0; i < n_in; i++)
+        if (!std::isfinite(psi[i])) return fail(HC_ERR_ARG, "state entry %zu is not finite", i);
     if (broadcast) {
-        if (h->scratch_d.ensure(D)) return HC_ERR_DEVICE;
-        HIP_TRY(hipMemcpyAsync(h->scratch_d.p, psi, (size_t)D * 8, hipMemcpyHostToDevice, h->stream));
+        if (h->scratch_d.ensure(n_in)) return HC_ERR_DEVICE;
+        HIP_TRY(hipMemcpyAsync(h->scratch_d.p, psi, n_in * 8, hipMemcpyHostToDevice, h->stream));
+        const long long per_point = broadcast == 2 ? h->n_members / h->n_points : h->n_members;
         hipLaunchKernelGGL(broadcast_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
-                           h->scratch_d.p, h->psi.p, D, (long long)h->n_members);
+                           h->scratch_d.p, h->psi.p, D, (long long)h->n_members, per_point);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));
     } else {
@@ -657,6 +796,8 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
     int rc = fill_args(h, A);
     if (rc) return rc;
     if (a->n_rows < 0) return fail(HC_ERR_ARG, "n_rows < 0");
+    if (a->spinup && a->accumulate_moments)
+        return fail(HC_ERR_ARG, "spin-up solves have no forcing row of their own: accumulate_moments must be 0");
     if (a->spinup) {
         if (a->row_begin < 0 || a->row_begin >= h->n_rows) return fail(HC_ERR_ARG, "spin-up forcing row out of range");
     } else if (a->row_begin < 1 || a->row_begin + a->n_rows > h->n_rows) {
@@ -701,8 +842,9 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
         if (rc) return rc;
         HIP_TRY(hipEventRecord(h->ev1, h->stream));
         if (a->accumulate_moments) {
-            hipLaunchKernelGGL(moments_kernel, dim3(chunk), dim3(256), 0, h->stream, h->wtd_u16.p, h->wtd_obs.p,
-                               (long long)N, (long long)row0, (int)a->spinup, (long long)h->n_rows, h->moments.p);
+            hipLaunchKernelGGL(moments_kernel, dim3(chunk, h->n_points), dim3(256), 0, h->stream, h->wtd_u16.p,
+                               h->wtd_obs.p, (long long)N, (long long)(N / h->n_points), (long long)row0,
+                               (long long)h->n_rows, h->moments.p);
             HIP_TRY(hipGetLastError());
         }
         if (a->wtd_out) {
@@ -816,28 +958,50 @@ int hc_synchronize(hc_handle *h)
     return HC_OK;
 }
 
+// the moment tables exist once forcing and column are known: [n_points][3][n_rows]
+static int ensure_moments(hc_handle *h)
+{
+    if (!h->have_forcing || !h->have_column) return fail(HC_ERR_ARG, "hc_set_column and hc_set_forcing must come first");
+    if (h->moments_points != h->n_points) {
+        const size_t cnt = (size_t)h->n_points * 3 * h->n_rows;
+        if (h->moments.ensure(cnt)) return HC_ERR_DEVICE;
+        HIP_TRY(hipMemset(h->moments.p, 0, cnt * 8));
+        h->moments_points = h->n_points;
+    }
+    return HC_OK;
+}
+
 int hc_get_moments(hc_handle *h, int64_t *moments)
 {
-    if (!h || !moments || !h->have_forcing) return fail(HC_ERR_ARG, "hc_get_moments: bad argument");
+    if (!h || !moments) return fail(HC_ERR_ARG, "hc_get_moments: bad argument");
     HIP_TRY(hipSetDevice(h->device));
+    if (int rc = ensure_moments(h)) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipMemcpy(moments, h->moments.p, (size_t)3 * h->n_rows * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(moments, h->moments.p, (size_t)h->n_points * 3 * h->n_rows * 8, hipMemcpyDeviceToHost));
     return HC_OK;
 }
 
 int hc_set_moments(hc_handle *h, const int64_t *moments)
 {
-    if (!h || !moments || !h->have_forcing) return fail(HC_ERR_ARG, "hc_set_moments: bad argument");
+    if (!h || !moments) return fail(HC_ERR_ARG, "hc_set_moments: bad argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpy(h->moments.p, moments, (size_t)3 * h->n_rows * 8, hipMemcpyHostToDevice));
+    if (int rc = ensure_moments(h)) return rc;
+    HIP_TRY(hipMemcpy(h->moments.p, moments, (size_t)h->n_points * 3 * h->n_rows * 8, hipMemcpyHostToDevice));
     return HC_OK;
 }
 
 int hc_reset_moments(hc_handle *h)
 {
-    if (!h || !h->have_forcing) return fail(HC_ERR_ARG, "hc_reset_moments: bad argument");
+    if (!h) return fail(HC_ERR_ARG, "hc_reset_moments: bad argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemset(h->moments.p, 0, (size_t)3 * h->n_rows * 8));
+    h->moments_points = 0;
+    return ensure_moments(h);
+}
+
+int hc_set_iteration_budget(hc_handle *h, int32_t phase_steps)
+{
+    if (!h || phase_steps < 1) return fail(HC_ERR_ARG, "hc_set_iteration_budget: bad argument");
+    h->max_phase_iterations = phase_steps;
     return HC_OK;
 }
 
@@ -848,6 +1012,7 @@ int hc_rhs(hc_handle *h, int64_t row, int32_t spinup, double *dydt, double *aux)
     int rc = fill_args(h, A);
     if (rc) return rc;
     if (row < 0 || row >= h->n_rows) return fail(HC_ERR_ARG, "row out of range");
+    if (h->n_points != 1) return fail(HC_ERR_UNSUPPORTED, "hc_rhs (test hook) serves one parameter point");
     HIP_TRY(hipSetDevice(h->device));
     const int D = h->p.dim_d;
     const size_t n = (size_t)h->n_members * D, na = (size_t)h->n_members * (3 * (D - 1) + 1);
@@ -885,6 +1050,54 @@ int hc_model_nodes(hc_handle *h, double *out, double *qinf)
     HIP_TRY(hipMemcpy(out, h->scratch_d.p, 4 * n * 8, hipMemcpyDeviceToHost));
     if (qinf) HIP_TRY(hipMemcpy(qinf, h->scratch_d.p + 4 * n, (size_t)h->n_members * 8, hipMemcpyDeviceToHost));
     return HC_OK;
+}
+
+int hc_plugin_eval(int device_ordinal, const hc_column_params *p, int64_t n_cells, int64_t n_cols,
+                   const double *psi, const double *por, const double *meank, const double *noisec,
+                   const double *n_rnd, double *out, double *qinf)
+{
+    if (!p || !psi || !por || !meank || !noisec || !n_rnd || !out || !qinf || n_cells < 1 || n_cols < 1)
+        return fail(HC_ERR_ARG, "hc_plugin_eval: bad argument");
+    if (!(p->n > 1.0) || !(p->alpha > 0.0) || !(p->dz > 0.0)) return fail(HC_ERR_ARG, "bad dz / n / alpha");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(HC_ERR_NO_DEVICE, "no HIP device visible (%s): the plugin call has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= count) return fail(HC_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    ColumnDev P{};
+    P.model = p->model;
+    P.theta_res = p->theta_res; P.alpha = p->alpha; P.n = p->n; P.m = p->m; P.psi_sat = p->psi_sat;
+    P.epsilon = p->epsilon; P.lambda = p->lambda_exp; P.sigma = p->sigma_noise; P.sat_soil = p->sat_soil;
+    P.dz = p->dz; P.inv_dz = 1.0 / p->dz;
+    P.mn_alpha = (p->m * p->n) * p->alpha;
+    P.inv_m = 1.0 / p->m;
+    const int special = (p->model == HC_MODEL_VRETTAS_FUNG && p->n == 2.0 && p->m == 0.5 && p->lambda_exp == 1.0);
+    const size_t nk = (size_t)n_cells, tot = nk * (size_t)n_cols;
+    DevBuf<double> in, res;
+    if (in.ensure(tot + 4 * nk) || res.ensure(4 * tot + (size_t)n_cols)) {
+        in.release(); res.release();
+        return HC_ERR_DEVICE;
+    }
+    int rc = [&]() -> int {
+        HIP_TRY(hipMemcpy(in.p, psi, tot * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(in.p + tot, por, nk * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(in.p + tot + nk, meank, nk * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(in.p + tot + 2 * nk, noisec, nk * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(in.p + tot + 3 * nk, n_rnd, nk * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(plugin_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, P, special,
+                           (long long)n_cells, (long long)n_cols, in.p, in.p + tot, in.p + tot + nk,
+                           in.p + tot + 2 * nk, in.p + tot + 3 * nk, res.p, res.p + 4 * tot);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, res.p, 4 * tot * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(qinf, res.p + 4 * tot, (size_t)n_cols * 8, hipMemcpyDeviceToHost));
+        return HC_OK;
+    }();
+    in.release();
+    res.release();
+    return rc;
 }
 
 }  // extern "C"

@@ -391,9 +391,12 @@ class ForcingDigest:
         self.dim_t = dim_t
         self.surface_evap = float(2.0 * np.sum(env["Evaporation_pct"] * precip) / dim_t)
         self.daylight = ((self.hour >= 6) & (self.hour <= 17)).astype(np.uint8)
+        # richards_pde.py:315 (PREDICT mode): the wet-season sink coefficient applies in Oct-Mar of the ROUNDED stamp
+        self.wet_season = np.isin(self.month_rounded, [10, 11, 12, 1, 2, 3]).astype(np.uint8)
         i = np.arange(dim_t)
         self.refresh = ((precip > 0.5) | (np.mod(i, 48) == 0)).astype(np.uint8)
         self.refresh[0] = 0                                   # row 0 is the initial state, never solved
+        self.refresh[self.wtd_obs < 0] = 0                    # a skipped row draws nothing (simulation.py:582-602)
         self.datenum = np.asarray(r_datenum, dtype=float)
 
 

@@ -185,60 +185,137 @@ class EnsembleSimulation:
 
     def wtd_mean_std(self, moments=None):
         m = self.moments() if moments is None else moments
-        return moments_to_mean_std(m, self.cols.dz)
+        return moments_to_mean_std(m, self.cols.dz, self.cols.z[0])
 
     def close(self):
         self.stepper.close()
 
 
-def allreduce_moments(moments, device):
-    """Sum the [3][T] int64 moment table over all ranks (RCCL when the backend is nccl).
+def allreduce_moments(moments, device, force=False):
+    """Sum the int64 moment table ([3][T], or [P][3][T] for P parameter points) over all ranks -- the one collective
+    of the path (RCCL over xGMI when the backend is nccl).
 
-    Integer sums are exact and order-independent, so the ensemble mean / sigma are bitwise
-    identical at any GPU count.  No-op when torch.distributed is not initialised.
-    """
+    Integer sums are exact and order-independent, so the ensemble mean / sigma are bitwise identical at any GPU
+    count.  With the nccl backend the table is reduced in device memory (one host->device copy of the table the
+    library handed over, ``all_reduce`` on the device tensor, one copy back).  No-op when torch.distributed is not
+    initialised or the world has one rank, unless ``force`` asks for the collective anyway (a world-size-1 process
+    group exercises the RCCL call path on a single GPU)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return moments
+    if dist.get_world_size() == 1 and not force:
         return moments
     t = torch.from_numpy(np.ascontiguousarray(moments))
     if dist.get_backend() == "nccl":
-        t = t.to(device)
+        t = t.to(device, non_blocking=False)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
 
 
-def parameter_sweep(params, data, well, points, n_members, n_rows, seed=0, device=0, rank=0, world=1):
+def merge_parameters(params, override):
+    """``params`` with the sections of ``override`` ({"Soil_Properties": {...}, ...}) merged in (a deep copy)."""
+    import copy
+    p = copy.deepcopy(params)
+    for section, values in override.items():
+        if isinstance(values, dict):
+            p.setdefault(section, {}).update(values)
+        else:
+            p[section] = values
+    return p
+
+
+class SweepSimulation:
+    """BASELINE config 5: P parameter points x ``n_members`` stochastic members each, ALL in one handle and one
+    launch per batch of rows (``hc_add_point``): per-member parameter point -> its own column parameters and slot
+    tables in the step kernel, per-point moments.
+
+    Global member ids are point-major over the WHOLE sweep: point k (global index ``first_point + j`` for the j-th
+    point of this handle) owns members [k n, (k + 1) n) of the Philox stream, so a point's realisations do not depend
+    on which rank or handle runs it.  Every point starts from its OWN spin-up (field capacity, wilting point and the
+    equilibrium profile depend on the point: porosity.py:172-181, simulation.py:389-493): the P spin-ups run
+    together in one ``hc_spinup`` launch (one member per point, that point's lead member's spin-up vector), and the
+    result is broadcast to the point's members."""
+
+    def __init__(self, cols_list, forcing, n_members, seed=0, device=0, first_point=0, flags=None, psi0=None):
+        self.points = list(cols_list)
+        self.P, self.n = len(self.points), int(n_members)
+        self.forcing, self.seed, self.device = forcing, int(seed), device
+        self.member_offset = int(first_point) * self.n
+        cols = self.points[0]
+        self.cols = cols
+        self.spinup_iters = None
+        if psi0 is None:
+            psi0, self.spinup_iters = self._spinup(flags)
+        self.psi0 = np.asarray(psi0, dtype=float).reshape(self.P, cols.dim_d)
+        self.stepper = EnsembleStepper(self.points, forcing, self.P * self.n, device=device, flags=flags)
+        self.stepper.set_state(self.psi0 if self.P > 1 else self.psi0[0])
+        self.stepper.set_noise_philox(self.seed, self.member_offset)
+        self.next_row, self.kernel_ms, self.launches = 1, 0.0, 0
+
+    def _spinup(self, flags):
+        cols, forcing, P, D = self.cols, self.forcing, self.P, self.cols.dim_d
+        lead = EnsembleStepper(self.points, forcing, P, device=self.device, flags=flags)
+        try:
+            lead.set_noise_philox(self.seed, 0)
+            noise = np.stack([lead.philox_normals(self.member_offset + j * self.n, PHILOX_DRAW_SPINUP)
+                              for j in range(P)])
+            start = np.stack([pressure_head(c, c.por_raw)[0] for c in self.points])
+            lead.set_state(start if P > 1 else start[0])
+            lead.set_noise_host(noise)
+            iters, _ = lead.spinup(forcing.zwtd_cm[0], cols.z[0], forcing_row=0, max_iterations=1500)
+            return lead.get_state(), iters
+        finally:
+            lead.close()
+
+    def advance(self, n_rows, **kw):
+        out = self.stepper.step_rows(self.next_row, n_rows, **kw)
+        self.next_row += n_rows
+        self.kernel_ms += out["kernel_ms"]
+        self.launches += out["launches"]
+        return out
+
+    def moments(self):
+        """[P][3][T]"""
+        return np.asarray(self.stepper.moments()).reshape(self.P, 3, self.forcing.dim_t)
+
+    def close(self):
+        self.stepper.close()
+
+
+def parameter_sweep(params, data, well, points, n_members, n_rows, seed=0, device=0, rank=0, world=1,
+                    one_launch=True, rows_per_call=48 * 8):
     """BASELINE config 5: a grid of (n, a0, psi_sat, ...) points x ``n_members`` realisations each.
 
-    ``points`` is a list of dicts ``{"Soil_Properties": {...}, "Hydraulic_Conductivity": {...}, ...}``
-    merged over ``params``.  Field capacity, wilting point, iPsi_50 and the spin-up equilibrium depend on
-    the point (porosity.py:172-181, simulation.py:339), so every point gets its own tables and its own
-    spin-up; whole points are dealt to ranks round-robin (rank r owns points r, r+world, ...), with no
-    communication.  Returns {point index: {"moments", "wtd_mean_cm", "wtd_std_cm", "psi0"}}.
+    ``points`` is a list of dicts ``{"Soil_Properties": {...}, "Hydraulic_Conductivity": {...}, ...}`` merged over
+    ``params``; every point gets its own tables and its own spin-up.  Contiguous blocks of whole points are dealt to
+    ranks (rank r owns points [r P / world, (r + 1) P / world)), with no communication.  ``one_launch`` (default)
+    steps all of a rank's points in one handle (:class:`SweepSimulation`); ``one_launch=False`` runs them one after
+    another, one handle each -- same global member ids, bit-identical results, kept as the cross-check.
+    Returns {point index: {"moments", "wtd_mean_cm", "wtd_std_cm", "psi0"}}.
     """
-    import copy
     from .digest import ColumnTables, ForcingDigest
+    P = len(points)
+    lo, hi = (rank * P) // world, ((rank + 1) * P) // world
+    mine = list(range(lo, hi))
+    if not mine:
+        return {}
+    cols_all = [ColumnTables(merge_parameters(params, points[k]), well) for k in mine]
+    forcing = ForcingDigest(params, data, cols_all[0])
+    groups = [(lo, cols_all)] if one_launch else [(k, [c]) for k, c in zip(mine, cols_all)]
     out = {}
-    for k, override in enumerate(points):
-        if k % world != rank:
-            continue
-        p = copy.deepcopy(params)
-        for section, values in override.items():
-            if isinstance(values, dict):
-                p.setdefault(section, {}).update(values)
-            else:
-                p[section] = values
-        cols = ColumnTables(p, well)
-        forcing = ForcingDigest(p, data, cols)
-        sim = EnsembleSimulation(cols, forcing, n_members, seed=seed + 7919 * k, device=device)
+    for first, cols_list in groups:
+        sim = SweepSimulation(cols_list, forcing, n_members, seed=seed, device=device, first_point=first)
         done = 0
         while done < n_rows:
-            n = min(48 * 8, n_rows - done)
+            n = min(rows_per_call, n_rows - done)
             sim.advance(n)
             done += n
         m = sim.moments()
-        mean_cm, std_cm = sim.wtd_mean_std(m)
-        out[k] = {"moments": m, "wtd_mean_cm": mean_cm, "wtd_std_cm": std_cm, "psi0": sim.psi0}
+        for j, c in enumerate(cols_list):
+            mean_cm, std_cm = moments_to_mean_std(m[j], c.dz, c.z[0])
+            out[first + j] = {"moments": m[j], "wtd_mean_cm": mean_cm, "wtd_std_cm": std_cm, "psi0": sim.psi0[j],
+                              "spinup_iterations": None if sim.spinup_iters is None else int(sim.spinup_iters[j]),
+                              "kernel_ms": sim.kernel_ms}
         sim.close()
     return out

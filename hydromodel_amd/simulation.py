@@ -18,12 +18,36 @@ from pathlib import Path
 import numpy as np
 from numpy.random import SeedSequence, default_rng
 
-from . import hdf5io
+from . import hdf5io, models
 from .digest import ColumnTables, ForcingDigest, load_site_well
 from .ensemble import spinup_on_gpu
 from .stepper import EnsembleStepper
 
 ROWS_PER_CALL = 240          # rows solved per library call in run(); bounds host buffers, not results
+
+
+def rows_noise(base, fresh, refresh, failed):
+    """The noise vector ``args_i["n_rnd"]`` holds AFTER the solve of each row of a batch -- what the diagnostics call
+    ``h_model(y_i, z, args_i)`` (simulation.py:623) sees.
+
+    ``base`` [D] is the base vector when the batch starts (modified in place, as the reference does), ``fresh``
+    [n_refresh][D] the vectors drawn for the batch's refresh rows, ``refresh`` / ``failed`` [n] the rows' refresh flag and
+    count of failed BDF attempts.  A non-refresh row shares the base array: every failed attempt scales it by 0.8 in
+    place (richards_pde.py:522), for this row and all later ones.  A refresh row owns its vector for that row only
+    (simulation.py:599-602); its failures damp that copy.  Successive multiplies, as the in-place ``*=`` does.
+    Returns [n][D]."""
+    out = np.empty((len(refresh), base.size))
+    k = 0
+    for i, (is_fresh, n_fail) in enumerate(zip(refresh, failed)):
+        if is_fresh:
+            v = np.array(fresh[k], dtype=float)
+            k += 1
+        else:
+            v = base
+        for _ in range(int(n_fail)):
+            v *= 0.8
+        out[i] = v
+    return out
 
 
 class Simulation(object):
@@ -49,9 +73,16 @@ class Simulation(object):
         cols = self.cols
         print(" Selected model: Vrettas-Fung" if cols.model == 0 else " Selected model: vanGenuchten")
         self.forcing = ForcingDigest(params, data, cols)
-        if cols.flags["PREDICT"]:
-            # richards_pde.py:327-330: np.linspace(..., low_lim) with a float count raises on the first RHS
+        if cols.flags["PREDICT"] and not (params.get("Ensemble") or {}).get("repair_predict"):
+            # richards_pde.py:327-330: np.linspace(..., low_lim) with a float count raises on the first RHS.  The
+            # stepper can run the repaired form (int count) on request: "Ensemble": {"repair_predict": true}
             raise TypeError("'numpy.float64' object cannot be interpreted as an integer")
+        # the objects the reference keeps in mData (simulation.py:208-231); h_model's call runs on the GPU
+        porous = models.Porosity(cols.z, cols.layers, cols.theta, cols.soil,
+                                 params["Hydrological_Model"]["Porosity_Profile"])
+        self.mData.update({"soil": cols.soil, "theta": cols.theta, "K": cols.k_hc, "porosity": porous,
+                           "hydro_model": models.make_model(params["Hydrological_Model"]["Name"], cols.soil, porous,
+                                                            cols.k_hc, cols.theta.res, cols.dz, device=self.device)})
         self.mData.update({"layers": cols.layers, "dz": cols.dz, "z_grid": cols.z, "sat_cells": cols.sat_cells,
                            "dim_t": self.forcing.dim_t, "zWtd_cm": self.forcing.zwtd_cm,
                            "precipitation_cm": self.forcing.precip, "atm": self.forcing.atm,
@@ -114,18 +145,19 @@ class Simulation(object):
                 fresh = np.empty((n_fresh, 1, D))
                 for k in range(n_fresh):                              # :601 one draw per refresh row, in order
                     fresh[k, 0] = self.rng.standard_normal(D)
+                base_before = st.get_noise_base()[0]
                 out = st.step_rows(row, n, fresh_noise=fresh, moments=False, want_wtd=True, want_psi=True,
-                                   want_diag=True)
+                                   want_diag=True, want_stats=True)
                 transp[row - 1:row - 1 + n] = out["diag"][:, 0, 0]
                 lateral[row - 1:row - 1 + n] = out["diag"][:, 0, 1]
                 psi[row:row + n] = out["psi"][:, 0, :]
                 wtd_est[row:row + n] = out["wtd"][:, 0]
                 abs_error[row:row + n] = np.abs(forcing.zwtd_cm[row:row + n] - z[wtd_est[row:row + n]])
-                # diagnostics h_model(y_i, z, args_i) (:623): refresh rows see their own vector, the
-                # others the base vector (as left by any x0.8 damping up to the end of this batch)
-                noise = np.tile(st.get_noise_base()[0], (n, 1))
-                is_fresh = forcing.refresh[row:row + n].astype(bool)
-                noise[is_fresh] = fresh[:, 0, :]
+                # diagnostics h_model(y_i, z, args_i) (:623) with the noise vector exactly as the row's solve left it
+                noise = rows_noise(base_before, fresh[:, 0, :], forcing.refresh[row:row + n], out["failed"][:, 0])
+                if not np.array_equal(base_before, st.get_noise_base()[0]):
+                    raise RuntimeError(f" {self.__class__.__name__}: the base noise vector rebuilt from the per-row"
+                                       f" failure counts differs from the library's (rows {row}..{row + n - 1}).")
                 self._diagnostics(psi[row:row + n], noise, theta_vol[row:row + n], k_hrc[row:row + n],
                                   k_bkg[row:row + n])
                 for i in range(row, row + n):

@@ -15,12 +15,12 @@ def column_params(cols, surface_evap, flags=None):
     fl = dict(cols.flags)
     if flags:
         fl.update(flags)
-    if fl.get("PREDICT"):
-        # richards_pde.py:327-330 raises TypeError on every NumPy >= 1.18 (float `low_lim`): the
-        # reference cannot run this mode, so there is nothing to match.
-        raise TypeError("'numpy.float64' object cannot be interpreted as an integer "
-                        "(PREDICT mode is broken in the reference: richards_pde.py:327-330)")
     p = L.ColumnParams()
+    # PREDICT: the reference raises TypeError at richards_pde.py:327-330 (np.linspace with a float count).  The stepper
+    # runs the repaired form -- `low_lim` as an int, nothing drains when it is <= 0 -- as a declared extension with
+    # no reference oracle; Simulation / the CLI only reach it with "Ensemble": {"repair_predict": true}.
+    p.flag_predict = int(bool(fl.get("PREDICT")))
+    p.sat_cells = int(cols.sat_cells)
     p.dim_d, p.model = cols.dim_d, cols.model
     p.flag_et, p.flag_lf, p.flag_hlift = int(fl["ET"]), int(fl["LF"]), int(fl["HLIFT"])
     p.n_root_first, p.n_root_int, p.n_groups = cols.n_root_first, cols.n_root_int, cols.n_groups
@@ -35,12 +35,21 @@ def column_params(cols, surface_evap, flags=None):
 
 
 class EnsembleStepper:
-    """N members x D depth nodes on one MI355X."""
+    """N members x D depth nodes on one MI355X.
+
+    ``cols`` is one ``digest.ColumnTables`` or a sequence of them (parameter points of a sweep sharing grid and
+    forcing): with P points the N members are point-major, point k owns members [k N/P, (k+1) N/P), and one launch
+    advances all of them; ``moments()`` then returns [P][3][T]."""
 
     def __init__(self, cols, forcing, n_members, device=0, flags=None):
         self.lib = L.load()
+        points = list(cols) if isinstance(cols, (list, tuple)) else [cols]
+        cols = points[0]
+        self.points, self.P = points, len(points)
         self.cols, self.forcing = cols, forcing
         self.D, self.N, self.T = cols.dim_d, int(n_members), forcing.dim_t
+        if self.N % self.P:
+            raise ValueError(f"{self.N} members do not divide into {self.P} parameter points")
         h = C.c_void_p()
         L.check(self.lib.hc_create(int(device), C.byref(h)))
         self.h = h
@@ -48,8 +57,15 @@ class EnsembleStepper:
         node, mid = L.as_f64(cols.node_table()), L.as_f64(cols.mid_table())
         groups = np.ascontiguousarray(cols.groups, dtype=np.int32)
         L.check(self.lib.hc_set_column(self.h, C.byref(self.params), L.dptr(node), L.dptr(mid), L.iptr(groups)))
+        for pt in points[1:]:
+            if pt.dim_d != self.D or not np.array_equal(pt.z, cols.z):
+                raise ValueError("parameter points must share the depth grid")
+            pp = column_params(pt, forcing.surface_evap, flags)
+            node, mid = L.as_f64(pt.node_table()), L.as_f64(pt.mid_table())
+            L.check(self.lib.hc_add_point(self.h, C.byref(pp), L.dptr(node), L.dptr(mid)))
         precip, atm = L.as_f64(forcing.precip), L.as_f64(forcing.atm)
-        day = np.ascontiguousarray(forcing.daylight, dtype=np.uint8)
+        # bit 0: daylight, bit 1: wet season (read in PREDICT mode only), include/hydrocol.h
+        day = np.ascontiguousarray(forcing.daylight | (forcing.wet_season << 1), dtype=np.uint8)
         wobs = np.ascontiguousarray(forcing.wtd_obs, dtype=np.int32)
         refr = np.ascontiguousarray(forcing.refresh, dtype=np.uint8)
         L.check(self.lib.hc_set_forcing(self.h, self.T, L.dptr(precip), L.dptr(atm), L.bptr(day),
@@ -76,8 +92,11 @@ class EnsembleStepper:
             L.check(self.lib.hc_set_state(self.h, L.dptr(psi), 1))
         elif psi.shape == (self.N, self.D):
             L.check(self.lib.hc_set_state(self.h, L.dptr(psi), 0))
+        elif psi.shape == (self.P, self.D):                       # one column per parameter point
+            L.check(self.lib.hc_set_state(self.h, L.dptr(psi), 2))
         else:
-            raise ValueError(f"state must be [{self.D}] or [{self.N}, {self.D}], got {psi.shape}")
+            raise ValueError(f"state must be [{self.D}], [{self.P}, {self.D}] (per point) or "
+                             f"[{self.N}, {self.D}], got {psi.shape}")
 
     def get_state(self, first=0, count=None):
         count = self.N - first if count is None else count
@@ -107,12 +126,16 @@ class EnsembleStepper:
 
     # -- stepping ------------------------------------------------------------------
     def n_refresh(self, row_begin, n_rows):
-        return int(self.forcing.refresh[row_begin:row_begin + n_rows].sum())
+        """Noise vectors rows [row_begin, row_begin + n_rows) consume: refresh rows that are actually solved (a row
+        whose observation is off the grid is skipped before anything is drawn, simulation.py:582-602)."""
+        sl = slice(row_begin, row_begin + n_rows)
+        return int((self.forcing.refresh[sl].astype(bool) & (self.forcing.wtd_obs[sl] >= 0)).sum())
 
     def step_rows(self, row_begin, n_rows, fresh_noise=None, spinup=False, moments=True,
                   want_wtd=False, want_stats=False, want_psi=False, want_diag=False):
         a = L.StepArgs()
-        a.row_begin, a.n_rows, a.spinup, a.accumulate_moments = int(row_begin), int(n_rows), int(spinup), int(moments)
+        a.row_begin, a.n_rows, a.spinup = int(row_begin), int(n_rows), int(spinup)
+        a.accumulate_moments = int(moments and not spinup)     # spin-up solves belong to no forcing row
         keep = []
         if fresh_noise is not None:
             fresh_noise = L.as_f64(fresh_noise)
@@ -135,6 +158,10 @@ class EnsembleStepper:
             out["diag"] = np.zeros((n_rows, self.N, 2))
             a.diag_out = L.dptr(out["diag"])
         L.check(self.lib.hc_step_rows(self.h, C.byref(a)))
+        if want_stats:
+            # slot 5 of the C-ABI record = refresh flag | failed attempts << 8 (include/hydrocol.h)
+            out["failed"] = out["stats"][:, :, 5] >> 8
+            out["stats"][:, :, 5] &= 0xFF
         self.last_kernel_ms, self.last_launches = a.kernel_ms, a.launches
         out["kernel_ms"], out["launches"] = a.kernel_ms, a.launches
         return out
@@ -147,13 +174,19 @@ class EnsembleStepper:
                 "guard_last_member": int(out[3]) >> 24, "guard_last_row": int(out[3]) & 0xFFFFFF}
 
     def moments(self):
-        m = np.zeros((3, self.T), dtype=np.int64)
+        """[3][T] (count, sum idx, sum idx^2 per forcing row); [P][3][T] when the handle holds P > 1 points."""
+        m = np.zeros((self.P, 3, self.T), dtype=np.int64)
         L.check(self.lib.hc_get_moments(self.h, L.lptr(m)))
-        return m
+        return m[0] if self.P == 1 else m
 
     def set_moments(self, m):
         m = np.ascontiguousarray(m, dtype=np.int64)
+        if m.size != self.P * 3 * self.T:
+            raise ValueError(f"moments must hold {self.P} x [3, {self.T}] values")
         L.check(self.lib.hc_set_moments(self.h, L.lptr(m)))
+
+    def set_iteration_budget(self, phase_steps):
+        L.check(self.lib.hc_set_iteration_budget(self.h, int(phase_steps)))
 
     def reset_moments(self):
         L.check(self.lib.hc_reset_moments(self.h))
@@ -187,10 +220,12 @@ class EnsembleStepper:
         return {"theta": out[0], "K": out[1], "C": out[2], "K_bkg": out[3], "q_inf_max": qinf}
 
 
-def moments_to_mean_std(moments, dz):
-    """mu/sigma of the water-table depth [cm] per row from (count, sum idx, sum idx^2)."""
-    cnt = moments[0].astype(np.float64)
+def moments_to_mean_std(moments, dz, z0=0.0):
+    """mu/sigma of the water-table depth [cm] per row from (count, sum idx, sum idx^2): the reference reports
+    ``z[wtd_est]`` with ``z[i] = z0 + i dz`` (simulation.py:140,612; ``z0 = well["soil"]``).  Accepts [3][T] or [P][3][T]."""
+    moments = np.asarray(moments)
+    cnt = moments[..., 0, :].astype(np.float64)
     with np.errstate(divide="ignore", invalid="ignore"):
-        mean_idx = moments[1] / cnt
-        var_idx = np.maximum(moments[2] / cnt - mean_idx ** 2, 0.0)
-    return dz * mean_idx, dz * np.sqrt(var_idx)
+        mean_idx = moments[..., 1, :] / cnt
+        var_idx = np.maximum(moments[..., 2, :] / cnt - mean_idx ** 2, 0.0)
+    return z0 + dz * mean_idx, dz * np.sqrt(var_idx)

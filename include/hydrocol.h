@@ -21,6 +21,12 @@
  *   hc_model_nodes     <- h_model(y_i, z, args_i) diagnostics call (src/simulation.py:623;
  *                         src/models/vrettas_fung.py:51 / vanGenuchten.py:23)
  *   hc_get_moments     <- (new) per-row ensemble moments of wtd_est (src/simulation.py:612)
+ *   hc_add_point       <- the per-parameter-point objects of Simulation.setupModel (src/simulation.py:146-231:
+ *                         SoilProperties / WaterContent / HydraulicConductivity / Porosity -> field capacity,
+ *                         wilting point src/porosity.py:172-181, iPsi_50 src/simulation.py:336-339), one set per
+ *                         point of a parameter sweep, all points stepped by ONE launch
+ *   hc_plugin_eval     <- HydrologicalModel subclasses called directly: VrettasFung.__call__(psi, z, {"n_rnd": ..})
+ *                         (src/models/vrettas_fung.py:51-257), vanGenuchten.__call__ (src/models/vanGenuchten.py:23-126)
  *
  * Conventions: every function returns 0 on success or a negative hc_status; nothing throws
  * or aborts across the boundary; hc_last_error() gives the thread-local message.  Host
@@ -63,6 +69,11 @@ typedef struct {
     int32_t n_groups;     /* FD-Jacobian column groups                                */
     double theta_res, alpha, n, m, psi_sat, epsilon, lambda_exp, sigma_noise, sat_soil, dz;
     double ipsi50, lai, surface_evap, interception, evap_delta_min;
+    /* Repaired PREDICT mode (src/richards_pde.py:312-351) -- an EXTENSION with no reference oracle: the reference
+     * raises TypeError at :327-330 (np.linspace with a float count).  Semantics here: low_lim = dim_d - (sat_cells - 1)
+     * of each pde_fun call as an integer, no cell drains when it is <= 0; needs the wet-season bit in `daylight`. */
+    int32_t flag_predict; /* Simulation_Flags.PREDICT (lateral flow in predictive mode, needs flag_lf)   */
+    int32_t sat_cells;    /* ceil(sat_depth / dz), src/simulation.py:128                                  */
 } hc_column_params;
 
 /* node_tabs: [3][D] rows = porosity, mean-K, noise coefficient (-1 = no layer) at the nodes
@@ -76,15 +87,26 @@ const char *hc_version(void);
 
 int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_tabs,
                   const double *mid_tabs, const int32_t *groups);
+/* Parameter points (BASELINE config 5).  hc_set_column installs point 0 and the geometry (dim_d, groups, dz) and
+ * drops any further points; hc_add_point appends one more point with tables of its own (same dim_d, n_groups, dz).
+ * With P points the n_members of hc_set_members must be a multiple of P and are point-major: point k owns members
+ * [k * n_members / P, (k + 1) * n_members / P).  One hc_step_rows / hc_spinup launch advances every point; each
+ * member sees the column parameters and tables of its own point; moments are kept per point. */
+int hc_add_point(hc_handle *h, const hc_column_params *p, const double *node_tabs, const double *mid_tabs);
+int hc_get_point_count(hc_handle *h); /* >= 1 once hc_set_column has run; negative on error */
 
 /* Forcing struct-of-arrays, n_rows entries each; wtd_obs < 0 marks a row to skip
- * (src/simulation.py:582-588); draw_idx[i] = index of the noise draw a refresh row uses
- * (1-based count of refresh rows up to and including i; 0 = base vector). */
+ * (src/simulation.py:582-588): such a row is not solved and consumes NO noise draw (its refresh flag is ignored,
+ * host-noise callers must not supply a vector for it).  The library numbers the draws itself: refresh row k
+ * (1-based, skipped rows not counted) uses draw k; 0 = base vector.
+ * daylight: bit 0 = daylight (6 <= hour <= 17, src/richards_pde.py:230); bit 1 = wet season, month in
+ * {10,11,12,1,2,3} (src/richards_pde.py:315) -- read only in PREDICT mode. */
 int hc_set_forcing(hc_handle *h, int64_t n_rows, const double *precip, const double *atm,
                    const uint8_t *daylight, const int32_t *wtd_obs, const uint8_t *refresh);
 
 int hc_set_members(hc_handle *h, int64_t n_members);
-/* psi: [n_members][D], or [D] when broadcast != 0 */
+/* psi: [n_members][D] (broadcast 0), [D] copied to every member (1), or [n_points][D] copied to the members of
+ * each parameter point (2) */
 int hc_set_state(hc_handle *h, const double *psi, int broadcast);
 int hc_get_state(hc_handle *h, double *psi, int64_t first_member, int64_t count);
 
@@ -110,7 +132,9 @@ typedef struct {
     int32_t accumulate_moments; /* add (count, sum idx, sum idx^2) of wtd_est per row          */
     const double *fresh_noise;  /* host-noise mode: [n_refresh_rows_in_range][n_members][D]    */
     int32_t *wtd_out;       /* nullable: [n_rows][n_members] wtd_est index per row             */
-    int32_t *stats_out;     /* nullable: [n_rows][n_members][6] nfev,njev,nlu,nsteps,attempts,refresh */
+    int32_t *stats_out;     /* nullable: [n_rows][n_members][6] nfev,njev,nlu,nsteps,attempts, then
+                               (refresh flag) | (failed attempts of the row << 8): each failed attempt scaled the
+                               row's noise vector by 0.8 (src/richards_pde.py:522)                      */
     double *psi_rows_out;   /* nullable: [n_rows][n_members][D] state after every row          */
     double *diag_out;       /* nullable: [n_rows][n_members][2] = transpiration, lateral_flow as
                                pde_model.arg_out holds them after the row's solve
@@ -138,14 +162,19 @@ int hc_spinup(hc_handle *h, hc_spinup_args *a);
 int hc_synchronize(hc_handle *h);
 /* event counters since hc_create: [0] FD-Jacobian passes that took num_jac's "difference too small ->
  * retry with a 10x step" branch, [1] failed BDF attempts (each scales the noise by 0.8), [2] attempts abandoned
- * by the kernel's iteration budget (60 000 phase steps, ~2 400x a typical attempt; handled like a solve that gave
- * up; with HYDROCOL_STRICT_GUARD=1 in the environment hc_step_rows / hc_spinup fail instead), [3] where the
+ * by the kernel's iteration budget (default 20 000 trips of the phase loop, ~14x the costliest regular attempt seen;
+ * a semantic deviation -- SciPy's BDF has no such cap -- handled like a solve that gave up, DESIGN.md "Iteration
+ * budget"; with HYDROCOL_STRICT_GUARD=1 in the environment hc_step_rows / hc_spinup fail instead), [3] where the
  * last of those happened: global member id << 24 | forcing row.
- * Test hooks read from the environment at hc_create: HYDROCOL_DEBUG_MAX_ITER (lowers that budget to force abandoned
- * attempts), HYDROCOL_DEBUG_JAC_REJECT (raises num_jac's retry threshold), HYDROCOL_ROWS_PER_LAUNCH. */
+ * Test hooks read from the environment at hc_create: HYDROCOL_DEBUG_MAX_ITER (same as hc_set_iteration_budget),
+ * HYDROCOL_DEBUG_JAC_REJECT (raises num_jac's retry threshold), HYDROCOL_ROWS_PER_LAUNCH, HYDROCOL_CHUNK_MEMBERS
+ * (members per scheduling chunk when several parameter points share a launch). */
 int hc_get_counters(hc_handle *h, uint64_t *out4);
+/* Budget of one BDF attempt in trips of the kernel's phase loop (>= 1). */
+int hc_set_iteration_budget(hc_handle *h, int32_t phase_steps);
 
-/* moments: [3][n_forcing_rows] int64 = count, sum(idx), sum(idx^2) of wtd_est over members */
+/* moments: [n_points][3][n_forcing_rows] int64 = count, sum(idx), sum(idx^2) of wtd_est over the members of each
+ * parameter point ([3][n_forcing_rows] for the usual single point); not available for spin-up solves */
 int hc_get_moments(hc_handle *h, int64_t *moments);
 int hc_set_moments(hc_handle *h, const int64_t *moments);
 int hc_reset_moments(hc_handle *h);
@@ -157,6 +186,15 @@ int hc_rhs(hc_handle *h, int64_t row, int32_t spinup, double *dydt, double *aux)
 /* plugin call on the nodes for every member's current state: out [4][n_members][D]
  * = theta, K, C, K_bkg; qinf [n_members] (nullable) */
 int hc_model_nodes(hc_handle *h, double *out, double *qinf);
+
+/* Stateless plugin call (needs a device, no handle): psi [n_cells][n_cols] depth-major as the reference's
+ * [dim_d x dim_m]; por / meank / noisec / n_rnd [n_cells] = porosity, layer-mean K (0 -> 1e-7, src/utilities.py:50),
+ * noise coefficient (0.05 / 0.10 / 1.0, -1 = cell in no layer) and N(0,1) value of every cell.
+ * out [4][n_cells][n_cols] = theta, K, C, K_bkg; qinf [n_cols] = q_inf_max from row 0 (src/models/vrettas_fung.py:254).
+ * Only model, theta_res, alpha, n, m, psi_sat, epsilon, lambda_exp, sigma_noise, sat_soil and dz of `p` are read. */
+int hc_plugin_eval(int device_ordinal, const hc_column_params *p, int64_t n_cells, int64_t n_cols,
+                   const double *psi, const double *por, const double *meank, const double *noisec,
+                   const double *n_rnd, double *out, double *qinf);
 
 #ifdef __cplusplus
 }

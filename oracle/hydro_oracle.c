@@ -285,7 +285,26 @@ static void pde_fun(const ho_column *c, const ho_row *r, int view, const double 
         for (int i = 0; i < k; i++) sat[i] = y[i] >= c->psi_sat;
         int wtd_obs = r->wtd_obs < k - 1 ? r->wtd_obs : k - 1;
         int wtd_est = ho_find_wtd(sat, k);
-        if (wtd_est < k && wtd_est < wtd_obs) {
+        if (c->flag_predict) {
+            /* ref: :312-351, repaired: low_lim = dim_d - (sat_cells - 1) as an int; np.linspace(1.5, 0.0, low_lim)
+             * with low_lim <= 0 is taken as "no cell may drain" (the reference raises: TypeError for the float count
+             * it passes, ValueError for a negative one, which the single-cell first call would hit). */
+            double alpha_low = r->wet ? -2.5e-3 : -1.5e-3;
+            int low_lim = k - (c->sat_cells - 1);
+            if (low_lim > 0 && wtd_est < low_lim) {
+                int j = wtd_est;
+                /* numpy.linspace: step = (stop - start) / (num - 1); y = arange(num) * step + start; y[-1] = stop */
+                double nu = 1.5;
+                if (low_lim > 1) {
+                    double step = -1.5 / (double)(low_lim - 1);
+                    nu = (double)j * step + 1.5;
+                    if (j == low_lim - 1) nu = 0.0;
+                }
+                double alpha_lat = alpha_low * (1.0 - pow((double)j / (double)low_lim, nu));
+                sink[j] = np_minimum(alpha_lat * y[j], sink[j]);
+                lat = fabs(sink[j]) * c->dz;
+            }
+        } else if (wtd_est < k && wtd_est < wtd_obs) {
             double lf[HO_MAXD];
             for (int j = wtd_est; j < wtd_obs; j++) {
                 sink[j] = np_minimum(-2.5e-4 * y[j], sink[j]);
@@ -869,7 +888,7 @@ void ho_run(const ho_column *c, int64_t T, const double *precip, const double *a
     for (int64_t i = row_begin; i < row_end; i++) {
         if (i == 0) continue;
         if (wtd_obs[i] < 0) continue; /* :582-588 observation not on the grid -> row skipped */
-        ho_row r = {precip[i], atm[i], daylight[i], wtd_obs[i], 0};
+        ho_row r = {precip[i], atm[i], daylight[i] & 1, wtd_obs[i], 0, (daylight[i] >> 1) & 1};
         double *noise = base_noise;          /* :592 the base vector, by reference */
         if (refresh[i]) {                    /* :599-602 fresh vector lives for this row only */
             noise = fresh + k_fresh * D;
@@ -907,7 +926,7 @@ void ho_run_diag(const ho_column *c, int64_t T, const double *precip, const doub
     (void)T;
     for (int64_t i = row_begin; i < row_end; i++) {
         if (i == 0 || wtd_obs[i] < 0) continue;
-        ho_row r = {precip[i], atm[i], daylight[i], wtd_obs[i], 0};
+        ho_row r = {precip[i], atm[i], daylight[i] & 1, wtd_obs[i], 0, (daylight[i] >> 1) & 1};
         double *noise = base_noise;
         if (refresh[i]) {
             noise = fresh + k_fresh * D;

@@ -41,11 +41,15 @@ typedef struct {
     const double *por_node, *meank_node, *noisec_node;                          /* [D]   */
     const double *por_mid, *fc_mid, *wlt_mid, *root_mid, *meank_mid, *noisec_mid; /* [D-1] */
     const int32_t *groups;                                                      /* [D]   */
+    /* repaired PREDICT mode (richards_pde.py:312-351 with `low_lim` cast to int, clamped at 0): an extension,
+     * the reference itself raises TypeError at :327-330 -- nothing pins this branch but its own formula */
+    int32_t flag_predict, sat_cells;
 } ho_column;
 
 typedef struct {
     double precip, atm;
     int32_t daylight, wtd_obs, spinup;
+    int32_t wet;   /* PREDICT mode: month in {10,11,12,1,2,3} (richards_pde.py:315) */
 } ho_row;
 
 typedef struct {
@@ -73,7 +77,8 @@ void ho_solve_row(const ho_column *c, const ho_row *r, double t0, double t1, con
                   double *n_rnd, double *y1, ho_stats *st, double *t_steps, int cap_steps);
 
 /* row loop of Simulation.run (simulation.py:561-626) for ONE member.
- * rows: [T]; base_noise [D] (mutated); fresh [n_refresh][D] consumed in row order (mutated);
+ * rows: [T] (daylight: bit 0 = daylight, bit 1 = wet season); base_noise [D] (mutated); fresh [n_refresh][D]
+ * consumed in row order (mutated);
  * outputs (nullable): wtd_est [T] (index), psi_out [T][D], per_row [T][6] = nfev,njev,nlu,nsteps,attempts,refresh */
 void ho_run(const ho_column *c, int64_t T, const double *precip, const double *atm,
             const uint8_t *daylight, const int32_t *wtd_obs, const uint8_t *refresh,

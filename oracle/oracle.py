@@ -27,12 +27,12 @@ class HoColumn(C.Structure):
                                            "surface_evap", "interception", "evap_delta_min")] +
                 [(k, _dp) for k in ("por_node", "meank_node", "noisec_node", "por_mid", "fc_mid",
                                     "wlt_mid", "root_mid", "meank_mid", "noisec_mid")] +
-                [("groups", _ip)])
+                [("groups", _ip), ("flag_predict", C.c_int32), ("sat_cells", C.c_int32)])
 
 
 class HoRow(C.Structure):
     _fields_ = [("precip", C.c_double), ("atm", C.c_double), ("daylight", C.c_int32),
-                ("wtd_obs", C.c_int32), ("spinup", C.c_int32)]
+                ("wtd_obs", C.c_int32), ("spinup", C.c_int32), ("wet", C.c_int32)]
 
 
 class HoStats(C.Structure):
@@ -100,8 +100,6 @@ class Oracle:
         fl = dict(cols.flags)
         if flags:
             fl.update(flags)
-        if fl.get("PREDICT"):
-            raise ValueError("PREDICT mode has no oracle (broken in the reference, SURVEY.md §5)")
         self._keep = {k: np.ascontiguousarray(getattr(cols, k), dtype=np.float64) for k in
                       ("por_node", "meank_node", "noisec_node", "por_mid", "fc_mid", "wlt_mid",
                        "root_mid", "meank_mid", "noisec_mid")}
@@ -119,6 +117,8 @@ class Oracle:
         for k, v in self._keep.items():
             setattr(c, k, _d(v))
         c.groups = self._groups.ctypes.data_as(_ip)
+        # repaired PREDICT mode: an extension, pinned by nothing but its own formula (hydro_oracle.h)
+        c.flag_predict, c.sat_cells = int(bool(fl.get("PREDICT"))), int(cols.sat_cells)
         self.c = c
         self.D = cols.dim_d
 
@@ -150,8 +150,8 @@ class Oracle:
 
     # -- RHS / solve -----------------------------------------------------------------
     @staticmethod
-    def row(precip, atm, daylight, wtd_obs, spinup=False):
-        return HoRow(float(precip), float(atm), int(daylight), int(wtd_obs), int(spinup))
+    def row(precip, atm, daylight, wtd_obs, spinup=False, wet=False):
+        return HoRow(float(precip), float(atm), int(daylight), int(wtd_obs), int(spinup), int(wet))
 
     def rhs(self, row, y, n_rnd, want_aux=False):
         y = np.ascontiguousarray(y, dtype=np.float64)
@@ -184,7 +184,7 @@ class Oracle:
         diag = np.zeros((T, 2))
         precip = np.ascontiguousarray(forcing.precip, dtype=np.float64)
         atm = np.ascontiguousarray(forcing.atm, dtype=np.float64)
-        day = np.ascontiguousarray(forcing.daylight, dtype=np.uint8)
+        day = np.ascontiguousarray(forcing.daylight | (forcing.wet_season << 1), dtype=np.uint8)
         wobs = np.ascontiguousarray(forcing.wtd_obs, dtype=np.int32)
         refr = np.ascontiguousarray(forcing.refresh, dtype=np.uint8)
         lib().ho_run_diag(C.byref(self.c), T, _d(precip), _d(atm), day.ctypes.data_as(_bp),
@@ -220,7 +220,7 @@ class Oracle:
         per_row = np.zeros((T, 6), dtype=np.int32) if want_stats else None
         precip = np.ascontiguousarray(forcing.precip, dtype=np.float64)
         atm = np.ascontiguousarray(forcing.atm, dtype=np.float64)
-        day = np.ascontiguousarray(forcing.daylight, dtype=np.uint8)
+        day = np.ascontiguousarray(forcing.daylight | (forcing.wet_season << 1), dtype=np.uint8)
         wobs = np.ascontiguousarray(forcing.wtd_obs, dtype=np.int32)
         refr = np.ascontiguousarray(forcing.refresh, dtype=np.uint8)
         lib().ho_run(C.byref(self.c), T, _d(precip), _d(atm), day.ctypes.data_as(_bp),
@@ -234,7 +234,7 @@ class Oracle:
         psi = np.array(psi_start, dtype=np.float64)
         n_rnd = np.array(n_rnd, dtype=np.float64)
         z = np.ascontiguousarray(self.cols.z, dtype=np.float64)
-        row0 = HoRow(row0.precip, row0.atm, row0.daylight, row0.wtd_obs, 1)
+        row0 = HoRow(row0.precip, row0.atm, row0.daylight, row0.wtd_obs, 1, row0.wet)
         it = lib().ho_spinup(C.byref(self.c), C.byref(row0), float(zwtd0_cm), _d(z), _d(psi), _d(n_rnd),
                              max_iter)
         return psi, it

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_struct_sizes():
     from hydromodel_amd import _lib
-    assert C.sizeof(_lib.ColumnParams) == 8 * 4 + 15 * 8
+    assert C.sizeof(_lib.ColumnParams) == 8 * 4 + 15 * 8 + 2 * 4          # static_assert'ed on the C side
     assert C.sizeof(_lib.StepArgs) == 8 + 8 + 4 + 4 + 5 * 8 + 8 + 8
     assert C.sizeof(_lib.SpinupArgs) == 8 + 4 + 4 + 8 + 8 + 8 + 8          # int32 + padding before the doubles
 

@@ -22,9 +22,10 @@ def _run(cmd, timeout=600):
 
 
 def test_bench_contract_one_rank():
-    out = _run([sys.executable, "bench.py", "--members", "4096", "--steps", "2", "--warmup", "1"])
+    out = _run([sys.executable, "bench.py", "--members", "4096", "--steps", "2", "--warmup", "1", "--cpu-seconds", "4",
+                "--sustained-members", "2048", "--sustained-days", "3"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sustained"):
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["dtype"] == "f64"
     assert out["unit"] == "column-days/s" and out["value"] > 1e4 and out["vs_baseline"] is None
@@ -36,6 +37,10 @@ def test_bench_contract_one_rank():
     assert r["algorithmic_bytes_per_launch"] == 4096 * 48 * (16 * 300 + 16)
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "members" in c["sample"]
+    assert c["cores"] == c["host_cores_usable"] and abs(c["per_core"] * c["cores"] - c["value"]) < 1e-9 * c["value"]
+    su = out["sustained"]
+    assert su["unit"] == "column-days/s" and su["members"] == 2048 and su["days"] == 3 and su["value"] > 1e3
+    assert su["failed_attempts"] >= 0 and su["guard_trips"] >= 0 and su["launches"] == 3
     assert out["value"] / c["value"] > 10            # a reported baseline, not a target -- but it must be the same unit
 
 
@@ -43,10 +48,11 @@ def test_bench_two_ranks_share_the_moments():
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                 "--master-addr", "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "2", "--backend", "gloo",
                 "--members", "2048", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
-    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["cpu_baseline"] is None
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["cpu_baseline"] is None and two["sustained"] is None
     # whole-job aggregate: both ranks' members over the max-over-ranks time
     assert abs(two["value"] - 2 * 2048 * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-6 * two["value"]
-    one = _run([sys.executable, "bench.py", "--members", "4096", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    one = _run([sys.executable, "bench.py", "--members", "4096", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                "--no-sustained"])
     # members are keyed by their global id: 2 x 2048 sharded == 4096 on one rank, to the last bit of the statistics
     assert two["wtd_mean_cm_last_row"] == one["wtd_mean_cm_last_row"]
     assert two["wtd_std_cm_last_row"] == one["wtd_std_cm_last_row"]

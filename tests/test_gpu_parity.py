@@ -562,36 +562,56 @@ def test_default_runs_never_take_the_retry_branch(gpu):
     st.close()
 
 
-def test_parameter_sweep_points_are_independent_runs(gpu):
-    """Config 5 in miniature: 4 (n, a0, psi_sat) points x 32 members; a point of the sweep equals the same point run alone."""
-    from hydromodel_amd.digest import ColumnTables, ForcingDigest
-    from hydromodel_amd.ensemble import EnsembleSimulation, parameter_sweep
+def test_parameter_sweep_points_are_independent_runs(gpu, monkeypatch):
+    """Config 5 in miniature: 4 (n, a0, psi_sat) points x 32 members stepped by ONE launch per batch of rows
+    (hc_add_point) equal the same points run one handle at a time, bit for bit -- states, spin-ups and moments --
+    whatever the scheduler's chunk size and however the points are dealt to ranks."""
+    from hydromodel_amd.ensemble import SweepSimulation, parameter_sweep
     from hydromodel_amd.synthetic import default_parameters
     from helpers import WELLS, forcing_frame
     params = default_parameters()
     pts = [{"Soil_Properties": {"n": n, "a0": a0, "psi_sat": ps}}
            for n, a0, ps in ((2.0, 0.009, -0.0047), (1.5, 0.003, -0.001), (3.0, 0.03, -1.0), (2.2, 0.012, -0.05))]
-    res = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, n_members=32, n_rows=48, seed=5)
+    res = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, n_members=32, n_rows=96, seed=5)
     assert sorted(res) == [0, 1, 2, 3]
     for k in res:
         m = res[k]["moments"]
-        assert np.array_equal(m[0, 1:49], np.full(48, 32)) and np.isfinite(res[k]["psi0"]).all()
+        assert m.shape == (3, 17520)
+        assert np.array_equal(m[0, 1:97], np.full(96, 32)) and np.isfinite(res[k]["psi0"]).all()
+        assert res[k]["spinup_iterations"] > 0
     assert not np.array_equal(res[0]["psi0"], res[2]["psi0"])          # the equilibrium depends on the point
-    # point 1 alone
-    import copy
-    p1 = copy.deepcopy(params)
-    p1["Soil_Properties"].update(pts[1]["Soil_Properties"])
-    cols = ColumnTables(p1, WELLS[200])
-    forcing = ForcingDigest(p1, forcing_frame(1), cols)
-    sim = EnsembleSimulation(cols, forcing, 32, seed=5 + 7919 * 1)
-    sim.advance(48)
-    assert np.array_equal(sim.moments(), res[1]["moments"])
-    sim.close()
-    # rank split: 2 "ranks" cover the grid exactly once
-    r0 = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, 32, 48, seed=5, rank=0, world=2)
-    r1 = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, 32, 48, seed=5, rank=1, world=2)
-    assert sorted(r0) == [0, 2] and sorted(r1) == [1, 3]
-    assert np.array_equal(r1[3]["moments"], res[3]["moments"])
+    assert not np.array_equal(res[0]["moments"], res[2]["moments"])
+    # the same points, one handle each
+    alone = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, n_members=32, n_rows=96, seed=5,
+                            one_launch=False)
+    for k in range(4):
+        assert np.array_equal(alone[k]["psi0"], res[k]["psi0"]), k
+        assert np.array_equal(alone[k]["moments"], res[k]["moments"]), k
+    # another chunking of the members
+    monkeypatch.setenv("HYDROCOL_CHUNK_MEMBERS", "5")
+    again = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, n_members=32, n_rows=96, seed=5)
+    monkeypatch.delenv("HYDROCOL_CHUNK_MEMBERS")
+    for k in range(4):
+        assert np.array_equal(again[k]["moments"], res[k]["moments"]), k
+    # rank split: 2 "ranks" cover the grid exactly once, contiguous blocks of points
+    r0 = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, 32, 96, seed=5, rank=0, world=2)
+    r1 = parameter_sweep(params, forcing_frame(1), WELLS[200], pts, 32, 96, seed=5, rank=1, world=2)
+    assert sorted(r0) == [0, 1] and sorted(r1) == [2, 3]
+    assert np.array_equal(r1[3]["moments"], res[3]["moments"]) and np.array_equal(r0[1]["moments"], res[1]["moments"])
+    # states, not only moments: the handle of all four points against point 2 alone
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import merge_parameters
+    cols_all = [ColumnTables(merge_parameters(params, p), WELLS[200]) for p in pts]
+    forcing = ForcingDigest(params, forcing_frame(1), cols_all[0])
+    psi0 = np.stack([res[k]["psi0"] for k in range(4)])
+    big = SweepSimulation(cols_all, forcing, 32, seed=5, psi0=psi0)
+    big.advance(48)
+    one = SweepSimulation([cols_all[2]], forcing, 32, seed=5, first_point=2, psi0=psi0[2])
+    one.advance(48)
+    assert np.array_equal(big.stepper.get_state(64, 32), one.stepper.get_state())
+    assert big.stepper.counters()["guard_trips"] == 0
+    big.close()
+    one.close()
 
 
 @pytest.mark.parametrize("fname,well,model,n_rows", [("g5s_vangenuchten_200.npz", 200, "vanGenuchten", 480),
@@ -858,7 +878,10 @@ def test_empty_launch_and_skipped_rows(gpu):
     out0 = st.step_rows(1, 0)
     assert out0["launches"] == 0 and np.array_equal(st.get_state(), np.tile(g["initial_cond"], (N, 1)))
     rows = 60
-    n_fresh = int(fc.refresh[1:1 + rows].sum())
+    fc.refresh = forcing.refresh.copy()
+    fc.refresh[fc.wtd_obs < 0] = 0                        # what ForcingDigest does: a skipped row draws nothing
+    n_fresh = st.n_refresh(1, rows)
+    assert n_fresh == int(forcing.refresh[1:1 + rows].sum()) - 1
     fresh = rng.standard_normal((n_fresh, N, D))
     out = st.step_rows(1, rows, fresh_noise=fresh, want_wtd=True, want_psi=True, want_stats=True)
     m = st.moments()
