@@ -71,12 +71,29 @@ def parse():
 
 
 def host_cores():
-    """Cores this process may run on (the GPU box gives a one-GPU job a share of the host), and the host's total."""
+    """(cores this process may use, cores of the host).  The GPU box gives a one-GPU job a SHARE of the host through a
+    cgroup CPU quota (cpu.max "1600000 100000" = 16 cores) while `nproc` / the affinity mask still show all 256:
+    threads beyond the quota only take turns."""
     total = os.cpu_count() or 1
     try:
         usable = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         usable = total
+    quota = None
+    try:                                            # cgroup v2
+        q, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:                                        # cgroup v1
+            q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            period = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        usable = min(usable, max(1, int(round(quota))))
     return max(1, min(usable, total)), total
 
 
@@ -112,7 +129,7 @@ def cpu_baseline(cols, forcing, psi0, threads, seconds, first_row=1 + ROWS_PER_D
             "per_core": days / wall / threads, "host_cores_total": total, "host_cores_usable": usable,
             "sample": f"{done} members x {rows} rows (days {(first_row - 1) // ROWS_PER_DAY + 1}.."
                       f"{(first_row - 1) // ROWS_PER_DAY + days_per_member}, D={D}) of the same forcing, C oracle, "
-                      f"{threads} threads (all cores usable by this process), {wall:.1f} s wall"}
+                      f"{threads} threads (every core this process may use: affinity mask and cgroup quota), {wall:.1f} s wall"}
 
 
 def sustained_leg(cols, forcing, psi0, members, days, seed, device):

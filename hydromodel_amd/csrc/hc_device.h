@@ -35,7 +35,7 @@ struct ColumnDev {
     // repaired PREDICT mode (richards_pde.py:312-351; an extension, the reference raises TypeError at :327-330):
     // low_lim = dim_d - (sat_cells - 1) of the interior call (k = D - 2 cells) as an int, 0 when not positive;
     // predict_first = 1 when the single-cell first-midpoint call has low_lim >= 1 (sat_cells <= 1)
-    int flag_predict, predict_low, predict_first, pad_;
+    int flag_predict, predict_low, predict_first, pad_;   // read only by the kernels built with PREDICT = true
 };
 
 struct RowDev {
@@ -646,7 +646,9 @@ __device__ __forceinline__ int deepest_true(const bool (&pred)[CPL])
 //          cell sits in the always-free slot (lane 63, c = CPL-1))
 // f[c]   : dy/dt at node lane*CPL + c (0 beyond the grid)
 // aux    : optional global pointer [3*(D-1)+1] receiving c | s | f at the midpoints and pL
-template <int CPL, bool SPECIAL>
+// PREDICT: the repaired predictive lateral flow is compiled in (a template parameter, not a run-time flag: the
+// branch costs 1.4 % of the monitoring-mode kernel through register allocation alone when it is merely present)
+template <int CPL, bool SPECIAL, bool PREDICT>
 __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, const double *tab,
                                          int lane, const double (&y)[CPL], const double (&rnd)[CPL],
                                          double (&f)[CPL], double *aux, double &diag_tr, double &diag_lf)
@@ -859,7 +861,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         int wtd_est = jstar < 0 ? 0 : jstar;                  // p* + 1
         wtd_est = wtd_est < k - 1 ? wtd_est : k - 1;
         const int wtd_obs = R.wtd_obs < k - 1 ? R.wtd_obs : k - 1;
-        if (P.flag_predict) {
+        if (PREDICT && P.flag_predict) {   // (a sweep may mix predictive and monitoring-mode points)
             // Predictive mode, richards_pde.py:312-351 with `low_lim` as an int (clamped at 0): ONE cell, the
             // estimated water table itself, drains with alpha_low (1 - (j / low_lim) ** nu[j]),
             // nu = linspace(1.5, 0, low_lim).  All of it is wave-uniform scalar work.

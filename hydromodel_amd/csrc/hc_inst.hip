@@ -1,0 +1,134 @@
+// hc_inst.hip -- the kernels of ONE cells-per-lane count (compile with -DHC_INST_CPL=N, N = 2..10): the step kernel and
+// the RHS hook, each for {specialised, generic exponents} x {monitoring, PREDICT lateral flow}.  See hc_launch.h.
+#include <cstdlib>
+
+#include "hc_launch.h"
+
+#ifndef HC_INST_CPL
+#error "compile with -DHC_INST_CPL=<cells per lane>"
+#endif
+
+namespace hc {
+
+// RHS hook: one wave per member, same device path as the stepper
+template <int CPL, bool SPECIAL, int WPB, bool PREDICT>
+__global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, long long row, double *dydt,
+                                                            double *aux)
+{
+    constexpr int SLOTS = WAVE * CPL;
+    extern __shared__ double lds[];
+    double *tab = lds;
+    double *nzbase = tab + NTAB * SLOTS;
+    for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
+    __syncthreads();
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const long long member = (long long)blockIdx.x * WPB + wave;
+    if (member >= A.n_members) return;
+    double *nz = nzbase + wave * SLOTS;
+    const ColumnDev P = load_const(A.P);
+    const IoArgs io = load_const(A.io);
+    const int D = P.D;
+    RowDev R;
+    R.precip = io.precip[row];
+    R.atm = io.atm[row];
+    R.daylight = io.daylight[row] & 1;
+    R.wet = (io.daylight[row] >> 1) & 1;
+    R.wtd_obs = io.wtd_obs[row];
+    R.spinup = A.spinup;
+    R.diag = 0;
+    double y[CPL], rnd[CPL], f[CPL];
+    double dtr = 0.0, dlf = 0.0;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = lane * CPL + c;
+        y[c] = i < D ? io.psi[member * D + i] : 0.0;
+        double z = 0.0;
+        if (i < D) {
+            if (A.host_noise)
+                z = io.base_noise[member * D + i];
+            else
+                z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), 0u, (unsigned)i) *
+                    io.nscale[member];
+        }
+        nz[c * WAVE + lane] = z;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = lane * CPL + c;
+        int idx = i >= 1 ? i - 1 : 0;
+        idx = (i < D - 1) ? idx : 0;
+        rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * nz[(idx % CPL) * WAVE + idx / CPL];
+    }
+#ifdef HC_PROFILE
+    // diagnostic build: repeat the evaluation (loop-carried through y) to time the RHS alone
+    for (long long rep = 1; rep < A.n_rows; rep++) {
+        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, nullptr, dtr, dlf);
+#pragma unroll
+        for (int c = 0; c < CPL; c++) y[c] = fma(f[c], 1e-300, y[c]);
+    }
+#endif
+    rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr, dtr, dlf);
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = lane * CPL + c;
+        if (i < D) dydt[member * D + i] = f[c];
+    }
+}
+
+
+namespace {
+
+template <int CPL, bool SPECIAL, bool PREDICT>
+hipError_t step_one(const LaunchCfg &cfg, const StepArgs &A)
+{
+    constexpr int WPB = wpb_of(CPL);
+    auto kern = step_kernel<CPL, SPECIAL, WPB, PREDICT>;
+    const size_t lds = step_lds_bytes(CPL, WPB);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(WPB * WAVE), lds, cfg.stream, A);
+    return hipGetLastError();
+}
+
+template <int CPL, bool SPECIAL, bool PREDICT>
+hipError_t rhs_one(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt, double *aux)
+{
+    constexpr int WPB = wpb_of(CPL);
+    auto kern = rhs_kernel<CPL, SPECIAL, WPB, PREDICT>;
+#ifdef HC_PROFILE
+    // diagnostic build: the step kernel's occupancy (one workgroup per CU) unless HYDROCOL_RHS_LDS_KB says otherwise
+    size_t lds = step_lds_bytes(CPL, WPB);
+    if (const char *e = getenv("HYDROCOL_RHS_LDS_KB")) lds = std::max(rhs_lds_bytes(CPL, WPB), (size_t)atoll(e) * 1024);
+#else
+    const size_t lds = rhs_lds_bytes(CPL, WPB);
+#endif
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(WPB * WAVE), lds, cfg.stream, A, row, dydt, aux);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+template <>
+hipError_t launch_step_cpl<HC_INST_CPL>(const LaunchCfg &cfg, const StepArgs &A)
+{
+    if (cfg.special)
+        return cfg.predict ? step_one<HC_INST_CPL, true, true>(cfg, A) : step_one<HC_INST_CPL, true, false>(cfg, A);
+    return cfg.predict ? step_one<HC_INST_CPL, false, true>(cfg, A) : step_one<HC_INST_CPL, false, false>(cfg, A);
+}
+
+template <>
+hipError_t launch_rhs_cpl<HC_INST_CPL>(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt, double *aux)
+{
+    if (cfg.special)
+        return cfg.predict ? rhs_one<HC_INST_CPL, true, true>(cfg, A, row, dydt, aux)
+                           : rhs_one<HC_INST_CPL, true, false>(cfg, A, row, dydt, aux);
+    return cfg.predict ? rhs_one<HC_INST_CPL, false, true>(cfg, A, row, dydt, aux)
+                       : rhs_one<HC_INST_CPL, false, false>(cfg, A, row, dydt, aux);
+}
+
+}  // namespace hc

@@ -1,0 +1,47 @@
+// hc_launch.h -- seam between the C-ABI host code (hydrocol.hip) and the kernel instantiations (hc_inst.hip).
+//
+// The step kernel exists per cells-per-lane count CPL = 2..10 x {special, generic exponents} x {monitoring, PREDICT
+// lateral flow}: 36 instantiations of a ~90 KB kernel.  One translation unit per CPL (hc_inst.hip compiled with
+// -DHC_INST_CPL=N) keeps them independent, so the build compiles them in parallel; the host code only sees the
+// launch functions below.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hc_step.h"
+
+namespace hc {
+
+struct LaunchCfg {
+    hipStream_t stream;
+    unsigned grid;       // workgroups
+    bool special;        // every parameter point has the default exponents (n = 2, m = 1/2, lambda = 1, vrettas_fung)
+    bool predict;        // repaired PREDICT lateral flow compiled in
+};
+
+// waves per workgroup per CPL: as many as the 160 KB of LDS admit (tables + per-wave vectors)
+constexpr int wpb_of(int cpl) { return cpl <= 5 ? 4 : (cpl <= 7 ? 3 : 2); }
+
+inline size_t step_lds_bytes(int cpl, int wpb)
+{
+    const size_t slots = (size_t)WAVE * cpl;
+    return NTAB * slots * 8 + 4 * slots * 1 + (size_t)wpb * ((size_t)nvec_of(cpl) * slots + WAVE_SCRATCH) * 8;
+}
+inline size_t rhs_lds_bytes(int cpl, int wpb)
+{
+    const size_t slots = (size_t)WAVE * cpl;
+    return NTAB * slots * 8 + (size_t)wpb * slots * 8;
+}
+
+// defined in hc_inst.hip, one explicit specialisation per translation unit
+template <int CPL> hipError_t launch_step_cpl(const LaunchCfg &cfg, const StepArgs &A);
+template <int CPL> hipError_t launch_rhs_cpl(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt,
+                                             double *aux);
+#define HC_DECLARE_CPL(N)                                                                    \
+    template <> hipError_t launch_step_cpl<N>(const LaunchCfg &cfg, const StepArgs &A);       \
+    template <> hipError_t launch_rhs_cpl<N>(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt, \
+                                             double *aux);
+HC_DECLARE_CPL(2) HC_DECLARE_CPL(3) HC_DECLARE_CPL(4) HC_DECLARE_CPL(5) HC_DECLARE_CPL(6)
+HC_DECLARE_CPL(7) HC_DECLARE_CPL(8) HC_DECLARE_CPL(9) HC_DECLARE_CPL(10)
+#undef HC_DECLARE_CPL
+
+}  // namespace hc

@@ -111,9 +111,9 @@ __device__ __forceinline__ T load_const(const T *p)
 
 // gamma = [0, cumsum(1/k)], alpha = (1 - kappa) * gamma, error_const = kappa * gamma + 1/(k+1)
 // with kappa = [0, -0.1850, -1/9, -0.0823, -0.0415, 0]  (bdf.py BDF.__init__), as NumPy evaluates them
-__device__ const double GAMMA_TAB[6] = {0.0, 1.0, 1.5, 1.8333333333333333, 2.083333333333333, 2.283333333333333};
-__device__ const double ALPHA_TAB[6] = {0.0, 1.185, 1.6666666666666667, 1.9842166666666667, 2.1697916666666663, 2.283333333333333};
-__device__ const double ERRC_TAB[6] = {1.0, 0.315, 0.16666666666666666, 0.09911666666666669, 0.11354166666666668, 0.16666666666666666};
+static __device__ const double GAMMA_TAB[6] = {0.0, 1.0, 1.5, 1.8333333333333333, 2.083333333333333, 2.283333333333333};
+static __device__ const double ALPHA_TAB[6] = {0.0, 1.185, 1.6666666666666667, 1.9842166666666667, 2.1697916666666663, 2.283333333333333};
+static __device__ const double ERRC_TAB[6] = {1.0, 0.315, 0.16666666666666666, 0.09911666666666669, 0.11354166666666668, 0.16666666666666666};
 __device__ __forceinline__ double gamma_k(int k) { return GAMMA_TAB[k]; }
 __device__ __forceinline__ double alpha_k(int k) { return ALPHA_TAB[k]; }
 __device__ __forceinline__ double error_const_k(int k) { return ERRC_TAB[k]; }
@@ -414,7 +414,7 @@ enum Phase {
     C_SUCCESS, C_FAIL
 };
 
-template <int CPL, bool SPECIAL, int WPB>
+template <int CPL, bool SPECIAL, int WPB, bool PREDICT>
 __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
 {
     constexpr int SLOTS = WAVE * CPL;
@@ -427,7 +427,11 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
     // [0] next member of the chunk, [1] its end (-1: no chunk left), [2] point whose tables are in LDS, [3] the chunk's point
     volatile int *chunk_state = reinterpret_cast<volatile int *>(gtab + NGTAB * SLOTS);
+#ifdef HC_SINGLE_POINT   // development builds: the scheduler of the multi-point mode compiled out (A/B timing)
+    constexpr bool multi = false;
+#else
     const bool multi = A.n_points > 1;
+#endif
     if (!multi)
         for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
     for (int k = threadIdx.x; k < NGTAB * SLOTS; k += WPB * WAVE) gtab[k] = (signed char)A.gtab[k];
@@ -517,8 +521,6 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         if (none_left) break;
     }
     point = __builtin_amdgcn_readfirstlane(point);
-    double psi_sat_m = A.psi_sat;
-    if (multi) psi_sat_m = load_const(A.P + point).psi_sat;
     bool vnode[CPL];
     int gs[CPL], gp[CPL], gn[CPL];
 #pragma unroll
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         phase = C_FAIL;
                     }
                     if (phase < C_SUCCESS) {
-                        rhs_eval<CPL, SPECIAL>(P, R, tab, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf);
+                        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf);
 #ifdef HC_PROFILE
                         const unsigned long long now = clock64();
                         if (lane == 0) prof_lds[16] += (unsigned)(now - prof_t);
@@ -1203,6 +1205,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         // ---- row epilogue: water table index (simulation.py:612), optional outputs
         bool unsat[CPL];
         double yv[CPL];
+        // psi_sat of the member's point: one scalar load per row rather than an SGPR pair held across the integrator
+        const double psi_sat_m = load_const(&A.P[point].psi_sat);
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
             yv[c] = V[V_Y * SLOTS + c * WAVE + lane];

@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "hc_step.h"
+#include "hc_launch.h"
 
 using namespace hc;
 
@@ -79,6 +79,8 @@ struct hc_handle {
     ColumnDev P{};               // point 0
     int cpl = 0, wpb = 0, slots = 0;
     bool special = false;        // every point is vrettas_fung with n = 2, m = 1/2, lambda = 1
+    bool force_generic = false;  // hc_set_generic_exponents: never take the specialised cell model
+    bool use_special() const { return special && !force_generic; }
     // parameter points (BASELINE config 5): host copies, uploaded by fill_args when `points_dirty`
     int n_points = 0, moments_points = 0;
     std::vector<ColumnDev> P_host;
@@ -170,72 +172,6 @@ __global__ void philox_dump(unsigned long long seed, long long member, unsigned 
     if (i < D) out[i] = philox_normal(seed, (unsigned long long)member, draw, (unsigned)i);
 }
 
-// RHS hook: one wave per member, same device path as the stepper
-template <int CPL, bool SPECIAL, int WPB>
-__global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, long long row, double *dydt,
-                                                            double *aux)
-{
-    constexpr int SLOTS = WAVE * CPL;
-    extern __shared__ double lds[];
-    double *tab = lds;
-    double *nzbase = tab + NTAB * SLOTS;
-    for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
-    __syncthreads();
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    const long long member = (long long)blockIdx.x * WPB + wave;
-    if (member >= A.n_members) return;
-    double *nz = nzbase + wave * SLOTS;
-    const ColumnDev P = load_const(A.P);
-    const IoArgs io = load_const(A.io);
-    const int D = P.D;
-    RowDev R;
-    R.precip = io.precip[row];
-    R.atm = io.atm[row];
-    R.daylight = io.daylight[row] & 1;
-    R.wet = (io.daylight[row] >> 1) & 1;
-    R.wtd_obs = io.wtd_obs[row];
-    R.spinup = A.spinup;
-    R.diag = 0;
-    double y[CPL], rnd[CPL], f[CPL];
-    double dtr = 0.0, dlf = 0.0;
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        const int i = lane * CPL + c;
-        y[c] = i < D ? io.psi[member * D + i] : 0.0;
-        double z = 0.0;
-        if (i < D) {
-            if (A.host_noise)
-                z = io.base_noise[member * D + i];
-            else
-                z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), 0u, (unsigned)i) *
-                    io.nscale[member];
-        }
-        nz[c * WAVE + lane] = z;
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        const int i = lane * CPL + c;
-        int idx = i >= 1 ? i - 1 : 0;
-        idx = (i < D - 1) ? idx : 0;
-        rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * nz[(idx % CPL) * WAVE + idx / CPL];
-    }
-#ifdef HC_PROFILE
-    // diagnostic build: repeat the evaluation (loop-carried through y) to time the RHS alone
-    for (long long rep = 1; rep < A.n_rows; rep++) {
-        rhs_eval<CPL, SPECIAL>(P, R, tab, lane, y, rnd, f, nullptr, dtr, dlf);
-#pragma unroll
-        for (int c = 0; c < CPL; c++) y[c] = fma(f[c], 1e-300, y[c]);
-    }
-#endif
-    rhs_eval<CPL, SPECIAL>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr, dtr, dlf);
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        const int i = lane * CPL + c;
-        if (i < D) dydt[member * D + i] = f[c];
-    }
-}
-
 // plugin call on the nodes (diagnostics), one thread per (member, node)
 __global__ void model_nodes_kernel(const StepArgs A, const double *node_tabs, int special, double *out,
                                    double *qinf)
@@ -298,85 +234,68 @@ __global__ void plugin_kernel(const ColumnDev P, int special, long long n_cells,
 // ------------------------------------------------------------------ launch dispatch
 namespace {
 
-size_t step_lds_bytes(int cpl, int wpb)
+// kernel launch through the per-CPL translation units (hc_launch.h)
+#ifdef HC_DEV_ONLY_CPL5
+#define HC_DISPATCH(FN, ...)                                        \
+    switch (h->cpl) {                                               \
+        case 3: err = FN<3>(__VA_ARGS__); break;                    \
+        case 5: err = FN<5>(__VA_ARGS__); break;                    \
+        default: return fail(HC_ERR_UNSUPPORTED, "development build: CPL 3 and 5 only"); \
+    }
+#else
+#define HC_DISPATCH(FN, ...)                                        \
+    switch (h->cpl) {                                               \
+        case 2: err = FN<2>(__VA_ARGS__); break;                    \
+        case 3: err = FN<3>(__VA_ARGS__); break;                    \
+        case 4: err = FN<4>(__VA_ARGS__); break;                    \
+        case 5: err = FN<5>(__VA_ARGS__); break;                    \
+        case 6: err = FN<6>(__VA_ARGS__); break;                    \
+        case 7: err = FN<7>(__VA_ARGS__); break;                    \
+        case 8: err = FN<8>(__VA_ARGS__); break;                    \
+        case 9: err = FN<9>(__VA_ARGS__); break;                    \
+        case 10: err = FN<10>(__VA_ARGS__); break;                  \
+        default:                                                    \
+            return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= %d", h->p.dim_d, \
+                        h->cpl, HC_MAX_DEPTH_NODES);                \
+    }
+#endif
+
+LaunchCfg launch_cfg(hc_handle *h, unsigned grid)
 {
-    const size_t slots = (size_t)WAVE * cpl;
-    return NTAB * slots * 8 + 4 * slots * 1 + (size_t)wpb * ((size_t)nvec_of(cpl) * slots + WAVE_SCRATCH) * 8;
-}
-size_t rhs_lds_bytes(int cpl, int wpb)
-{
-    const size_t slots = (size_t)WAVE * cpl;
-    return NTAB * slots * 8 + (size_t)wpb * slots * 8;
+    // PREDICT is per point in the tables but one kernel serves the launch: any predictive point selects the build
+    // with the branch compiled in; a monitoring-mode point inside such a launch keeps its own semantics (flag_predict)
+    bool predict = false;
+    for (const ColumnDev &P : h->P_host) predict = predict || P.flag_predict;
+    return LaunchCfg{h->stream, grid, h->use_special(), predict};
 }
 
-template <int CPL, bool SPECIAL, int WPB>
-int launch_step_t(hc_handle *h, const StepArgs &A)
+int launch_step(hc_handle *h, const StepArgs &A)
 {
-    auto kern = step_kernel<CPL, SPECIAL, WPB>;
-    const size_t lds = step_lds_bytes(CPL, WPB);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+    const int wpb = wpb_of(h->cpl);
     // persistent grid: LDS admits one workgroup per CU; fewer workgroups when there are fewer members
-    const long long want = (A.n_members + WPB - 1) / WPB;
+    const long long want = (A.n_members + wpb - 1) / wpb;
     const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->n_cu);
     HIP_TRY(hipMemsetAsync(h->counters.p + 63, 0, sizeof(unsigned long long), h->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * WAVE), lds, h->stream, A);
-    HIP_TRY(hipGetLastError());
+    hipError_t err = hipSuccess;
+    HC_DISPATCH(launch_step_cpl, launch_cfg(h, grid), A);
+    HIP_TRY(err);
     return HC_OK;
 }
 
-template <int CPL, bool SPECIAL, int WPB>
-int launch_rhs_t(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
+int launch_rhs(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
 {
-    auto kern = rhs_kernel<CPL, SPECIAL, WPB>;
-#ifdef HC_PROFILE
-    // diagnostic build: the step kernel's occupancy (one workgroup per CU) unless HYDROCOL_RHS_LDS_KB says otherwise
-    size_t lds = step_lds_bytes(CPL, WPB);
-    if (const char *e = getenv("HYDROCOL_RHS_LDS_KB")) lds = std::max(rhs_lds_bytes(CPL, WPB), (size_t)atoll(e) * 1024);
-#else
-    const size_t lds = rhs_lds_bytes(CPL, WPB);
-#endif
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    const unsigned grid = (unsigned)((A.n_members + WPB - 1) / WPB);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * WAVE), lds, h->stream, A, row, dydt, aux);
-    HIP_TRY(hipGetLastError());
+    const int wpb = wpb_of(h->cpl);
+    const unsigned grid = (unsigned)((A.n_members + wpb - 1) / wpb);
+    hipError_t err = hipSuccess;
+    HC_DISPATCH(launch_rhs_cpl, launch_cfg(h, grid), A, row, dydt, aux);
+    HIP_TRY(err);
     return HC_OK;
 }
-
-// waves per workgroup per CPL: as many as the 160 KB of LDS admit (tables + per-wave vectors)
-#ifdef HC_DEV_ONLY_CPL5
-#define HC_DISPATCH(FN, ...)                                                            \
-    if (h->cpl == 5) return h->special ? FN<5, true, 4>(__VA_ARGS__) : FN<5, false, 4>(__VA_ARGS__); \
-    if (h->cpl == 3 && h->special) return FN<3, true, 4>(__VA_ARGS__);                  \
-    return fail(HC_ERR_UNSUPPORTED, "development build: CPL 5 only")
-#else
-#define HC_DISPATCH(FN, ...)                                                            \
-    switch (h->cpl) {                                                                   \
-        case 2: return h->special ? FN<2, true, 4>(__VA_ARGS__) : FN<2, false, 4>(__VA_ARGS__); \
-        case 3: return h->special ? FN<3, true, 4>(__VA_ARGS__) : FN<3, false, 4>(__VA_ARGS__); \
-        case 4: return h->special ? FN<4, true, 4>(__VA_ARGS__) : FN<4, false, 4>(__VA_ARGS__); \
-        case 5: return h->special ? FN<5, true, 4>(__VA_ARGS__) : FN<5, false, 4>(__VA_ARGS__); \
-        case 6: return h->special ? FN<6, true, 3>(__VA_ARGS__) : FN<6, false, 3>(__VA_ARGS__); \
-        case 7: return h->special ? FN<7, true, 3>(__VA_ARGS__) : FN<7, false, 3>(__VA_ARGS__); \
-        case 8: return h->special ? FN<8, true, 2>(__VA_ARGS__) : FN<8, false, 2>(__VA_ARGS__); \
-        case 9: return h->special ? FN<9, true, 2>(__VA_ARGS__) : FN<9, false, 2>(__VA_ARGS__); \
-        case 10: return h->special ? FN<10, true, 2>(__VA_ARGS__) : FN<10, false, 2>(__VA_ARGS__); \
-        default: break;                                                                 \
-    }                                                                                   \
-    return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= %d", h->p.dim_d, h->cpl, \
-                HC_MAX_DEPTH_NODES)
-#endif
 
 int push_io(hc_handle *h)
 {
     HIP_TRY(hipMemcpyAsync(h->iodev.p, &h->io_host, sizeof(IoArgs), hipMemcpyHostToDevice, h->stream));
     return HC_OK;
-}
-int launch_step(hc_handle *h, const StepArgs &A) { HC_DISPATCH(launch_step_t, h, A); }
-int launch_rhs(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
-{
-    HC_DISPATCH(launch_rhs_t, h, A, row, dydt, aux);
 }
 
 int fill_args(hc_handle *h, StepArgs &A)
@@ -998,6 +917,13 @@ int hc_reset_moments(hc_handle *h)
     return ensure_moments(h);
 }
 
+int hc_set_generic_exponents(hc_handle *h, int32_t on)
+{
+    if (!h) return fail(HC_ERR_ARG, "NULL handle");
+    h->force_generic = on != 0;
+    return HC_OK;
+}
+
 int hc_set_iteration_budget(hc_handle *h, int32_t phase_steps)
 {
     if (!h || phase_steps < 1) return fail(HC_ERR_ARG, "hc_set_iteration_budget: bad argument");
@@ -1044,7 +970,7 @@ int hc_model_nodes(hc_handle *h, double *out, double *qinf)
     rc = push_io(h);
     if (rc) return rc;
     hipLaunchKernelGGL(model_nodes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, A,
-                       h->node_tabs.p, (int)h->special, h->scratch_d.p, h->scratch_d.p + 4 * n);
+                       h->node_tabs.p, (int)h->use_special(), h->scratch_d.p, h->scratch_d.p + 4 * n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(out, h->scratch_d.p, 4 * n * 8, hipMemcpyDeviceToHost));

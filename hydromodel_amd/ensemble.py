@@ -249,6 +249,9 @@ class SweepSimulation:
             psi0, self.spinup_iters = self._spinup(flags)
         self.psi0 = np.asarray(psi0, dtype=float).reshape(self.P, cols.dim_d)
         self.stepper = EnsembleStepper(self.points, forcing, self.P * self.n, device=device, flags=flags)
+        # a sweep always runs the generic-exponent cell model: a point that happens to sit on the default exponents
+        # must not change its bits with the company it is stepped in
+        self.stepper.set_generic_exponents(True)
         self.stepper.set_state(self.psi0 if self.P > 1 else self.psi0[0])
         self.stepper.set_noise_philox(self.seed, self.member_offset)
         self.next_row, self.kernel_ms, self.launches = 1, 0.0, 0
@@ -257,6 +260,7 @@ class SweepSimulation:
         cols, forcing, P, D = self.cols, self.forcing, self.P, self.cols.dim_d
         lead = EnsembleStepper(self.points, forcing, P, device=self.device, flags=flags)
         try:
+            lead.set_generic_exponents(True)
             lead.set_noise_philox(self.seed, 0)
             noise = np.stack([lead.philox_normals(self.member_offset + j * self.n, PHILOX_DRAW_SPINUP)
                               for j in range(P)])

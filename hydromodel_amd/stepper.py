@@ -185,6 +185,10 @@ class EnsembleStepper:
             raise ValueError(f"moments must hold {self.P} x [3, {self.T}] values")
         L.check(self.lib.hc_set_moments(self.h, L.lptr(m)))
 
+    def set_generic_exponents(self, on=True):
+        """Pin the generic-exponent cell model (include/hydrocol.h): same bits for a point alone or inside a sweep."""
+        L.check(self.lib.hc_set_generic_exponents(self.h, int(bool(on))))
+
     def set_iteration_budget(self, phase_steps):
         L.check(self.lib.hc_set_iteration_budget(self.h, int(phase_steps)))
 

@@ -94,6 +94,12 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
  * member sees the column parameters and tables of its own point; moments are kept per point. */
 int hc_add_point(hc_handle *h, const hc_column_params *p, const double *node_tabs, const double *mid_tabs);
 int hc_get_point_count(hc_handle *h); /* >= 1 once hc_set_column has run; negative on error */
+/* The cell model comes in two builds: one specialised for the reference's default exponents (vrettas_fung, n = 2,
+ * m = 1/2, lambda = 1: every pow() folds into rsqrt / multiplies) and a generic one (powers as exp(y log x)); a handle
+ * takes the first only when EVERY point qualifies.  The two agree to ~1e-15 relative per call, not bit for bit.
+ * on != 0 pins the generic build, so that a default-exponent point gives the same bits whether it is stepped alone or
+ * inside a sweep of other points. */
+int hc_set_generic_exponents(hc_handle *h, int32_t on);
 
 /* Forcing struct-of-arrays, n_rows entries each; wtd_obs < 0 marks a row to skip
  * (src/simulation.py:582-588): such a row is not solved and consumes NO noise draw (its refresh flag is ignored,
