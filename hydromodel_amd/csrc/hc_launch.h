@@ -18,13 +18,13 @@ struct LaunchCfg {
     bool predict;        // repaired PREDICT lateral flow compiled in
 };
 
-// waves per workgroup per CPL: as many as the 160 KB of LDS admit (tables + per-wave vectors)
-constexpr int wpb_of(int cpl) { return cpl <= 5 ? 4 : (cpl <= 7 ? 3 : 2); }
+// four waves per workgroup (one per SIMD) at every depth: what does not fit in LDS lives in StepArgs::wave_spill
+constexpr int wpb_of(int) { return WAVES_PER_BLOCK; }
 
 inline size_t step_lds_bytes(int cpl, int wpb)
 {
     const size_t slots = (size_t)WAVE * cpl;
-    return NTAB * slots * 8 + 4 * slots * 1 + (size_t)wpb * ((size_t)nvec_of(cpl) * slots + WAVE_SCRATCH) * 8;
+    return NTAB * slots * 8 + 4 * slots * 1 + (size_t)wpb * ((size_t)lds_vectors(cpl) * slots + WAVE_SCRATCH) * 8;
 }
 inline size_t rhs_lds_bytes(int cpl, int wpb)
 {

@@ -29,17 +29,96 @@ constexpr double NUM_JAC_DIFF_SMALL = 1.8189894035458565e-12;
 constexpr double NUM_JAC_DIFF_BIG = 0.0001220703125;
 constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 
-// per-wave LDS vectors (each 64*CPL doubles)
-// per-wave LDS vectors.  V_NZ (the row's noise vector) comes last so that the deep-column variants can leave it out:
-// beyond CPL = 6 every vector costs a wave of occupancy, and the noise can be re-read / regenerated per attempt.
-enum { V_Y = 0, V_FP, V_FAC, V_D0, V_NZ = V_D0 + MAX_ORDER + 3, NVEC = V_NZ + 1 };
-__host__ __device__ constexpr bool nz_in_lds(int cpl) { return cpl <= 6 || cpl == 8; }
-__host__ __device__ constexpr int nvec_of(int cpl) { return nz_in_lds(cpl) ? NVEC : NVEC - 1; }
+// Per-wave vectors (each 64*CPL doubles): the accepted state, the base f of a Jacobian, the FD step factors, the BDF
+// difference rows D[0..7] and the row's noise vector.
+// V_Y0, the state a row starts from, is only needed again when an attempt fails: deep columns (CPL > 5) keep it in the
+// global region instead of registers, shallower ones never use it.  (Parking the Jacobian rows and column steps there
+// as well was measured at D = 401 / 461 / 581: 7 % slower -- the compiler's own scratch placement does better.)
+enum { V_Y = 0, V_FP, V_FAC, V_D0, V_NZ = V_D0 + MAX_ORDER + 3, NVEC = V_NZ + 1, V_Y0 = NVEC };
 #ifdef HC_PROFILE
 constexpr int WAVE_SCRATCH = 192;
 #else
 constexpr int WAVE_SCRATCH = 160;
 #endif
+constexpr int WAVES_PER_BLOCK = 4;          // one wave per SIMD for every column depth
+constexpr int LDS_BYTES = 160 * 1024;
+// Where they live.  Up to CPL = 5 (D <= 320) all twelve fit in LDS next to the shared tables with four waves per
+// workgroup.  Deeper columns keep four waves per CU -- every SIMD busy -- by moving the vectors that are touched least
+// to a per-wave region in global memory (L2 / Infinity-Cache resident: 1 024 waves x <= 31 KB): first D[7], the FD
+// factors (read and written by Jacobian evaluations only, ~1.2 per row), D[6], the Jacobian's base f and the accepted
+// state (both written once per step or accepted step -- fire-and-forget stores -- and read once per Jacobian / row),
+// then D[5], D[4].  Every lane only ever touches its own slots of these, so program order is all the ordering needed.
+// The noise vector is read across lanes (cell j uses n_rnd[j-1]): it is either in LDS (CPL <= 6) or rebuilt per attempt.
+__host__ __device__ constexpr int lds_vectors(int cpl)      // how many of the twelve fit, four waves per workgroup
+{
+    const int slots = 64 * cpl;
+    const int tables = NTAB * slots * 8 + 4 * slots;
+    const int n = ((LDS_BYTES - tables) / WAVES_PER_BLOCK - WAVE_SCRATCH * 8) / (slots * 8);
+    return n < NVEC ? n : NVEC;
+}
+__host__ __device__ constexpr bool nz_in_lds(int cpl) { return cpl <= 6; }
+__host__ __device__ constexpr int lds_listed(int cpl)       // ... of the eleven vectors other than the noise
+{
+    const int n = lds_vectors(cpl) - (nz_in_lds(cpl) ? 1 : 0);
+    return n < NVEC - 1 ? n : NVEC - 1;
+}
+__host__ __device__ constexpr int spill_vectors(int cpl) { return NVEC - lds_listed(cpl); }   // incl. V_Y0
+// rank of a vector in the keep-in-LDS order D0..D5, Y, FP, D6, FAC, D7 (, Y0: never in LDS)
+__host__ __device__ constexpr int vec_rank(int v)
+{
+    return v == V_Y0 ? 11 : v == V_Y ? 6 : v == V_FP ? 7 : v == V_FAC ? 9 : v == V_D0 + 6 ? 8 : v == V_D0 + 7 ? 10 : v - V_D0;
+}
+
+// A wave's vectors: `lds` holds the first lds_listed(CPL) of the order above (then the noise vector, if it is in LDS),
+// `spill` the rest.  VEC is a compile-time id; the D-row accessors take the row as an unrolled loop index.
+template <int CPL>
+struct WaveVecs {
+    static constexpr int SLOTS = WAVE * CPL;
+    static constexpr int N_LDS = lds_listed(CPL);
+    double *lds;
+    __attribute__((address_space(1))) double *spill;
+    template <int VEC>
+    __device__ __forceinline__ double ld(int slot) const
+    {
+        if constexpr (VEC == V_NZ) return lds[N_LDS * SLOTS + slot];
+        else if constexpr (vec_rank(VEC) < N_LDS) return lds[vec_rank(VEC) * SLOTS + slot];
+        else return spill[(vec_rank(VEC) - N_LDS) * SLOTS + slot];
+    }
+    template <int VEC>
+    __device__ __forceinline__ void st(int slot, double v) const
+    {
+        if constexpr (VEC == V_NZ) lds[N_LDS * SLOTS + slot] = v;
+        else if constexpr (vec_rank(VEC) < N_LDS) lds[vec_rank(VEC) * SLOTS + slot] = v;
+        else spill[(vec_rank(VEC) - N_LDS) * SLOTS + slot] = v;
+    }
+    // D[k]: k is a constant after unrolling, the switch folds away
+    __device__ __forceinline__ double ldD(int k, int slot) const
+    {
+        switch (k) {
+            case 0: return ld<V_D0 + 0>(slot);
+            case 1: return ld<V_D0 + 1>(slot);
+            case 2: return ld<V_D0 + 2>(slot);
+            case 3: return ld<V_D0 + 3>(slot);
+            case 4: return ld<V_D0 + 4>(slot);
+            case 5: return ld<V_D0 + 5>(slot);
+            case 6: return ld<V_D0 + 6>(slot);
+            default: return ld<V_D0 + 7>(slot);
+        }
+    }
+    __device__ __forceinline__ void stD(int k, int slot, double v) const
+    {
+        switch (k) {
+            case 0: st<V_D0 + 0>(slot, v); break;
+            case 1: st<V_D0 + 1>(slot, v); break;
+            case 2: st<V_D0 + 2>(slot, v); break;
+            case 3: st<V_D0 + 3>(slot, v); break;
+            case 4: st<V_D0 + 4>(slot, v); break;
+            case 5: st<V_D0 + 5>(slot, v); break;
+            case 6: st<V_D0 + 6>(slot, v); break;
+            default: st<V_D0 + 7>(slot, v); break;
+        }
+    }
+};
 // Iteration budget of one BDF attempt (loop trips of the phase machine; a hard row needs a few hundred).  It is part of
 // the semantics at scale: on a state that slides along a discontinuity of the RHS (psi_sat / lateral-flow switch) Newton
 // only converges for h ~ 1e-11, the step controller cycles "halve, halve, halve, accept twice, x10" forever and time
@@ -79,6 +158,7 @@ constexpr int HC_TRACE_N = 20000;
 struct StepArgs {
     const ColumnDev *P;       // device memory, [n_points]
     const IoArgs *io;         // device memory
+    double *wave_spill;       // [grid * 4 waves][spill_vectors(CPL)][SLOTS]: per-wave vectors that do not fit in LDS, or null
     const double *tab;        // [n_points][NTAB][SLOTS]
     const int *gtab;          // [NGTAB][SLOTS]
     long long n_members;
@@ -140,7 +220,7 @@ __device__ __forceinline__ double rms_ratio(const double (&x)[CPL], const double
 // R[i][j] = prod_{q=1..i} (q-1-factor*j)/q (R[0][j] = 1, R[i>0][0] = 0); lanes 0..35 build R and U = R(.,1)
 // in LDS, lanes 0..35 form RU, then every lane applies RU^T to its cells.
 template <int CPL, int ORDER>
-__device__ __forceinline__ void apply_RU(double *Dv, const double *ru, int lane)
+__device__ __forceinline__ void apply_RU(const WaveVecs<CPL> &W, const double *ru, int lane)
 {
     constexpr int SLOTS = WAVE * CPL;
     double m[ORDER + 1][ORDER + 1];
@@ -153,13 +233,13 @@ __device__ __forceinline__ void apply_RU(double *Dv, const double *ru, int lane)
         const int slot = c * WAVE + lane;
         double col[ORDER + 1];
 #pragma unroll
-        for (int k = 0; k <= ORDER; k++) col[k] = Dv[k * SLOTS + slot];
+        for (int k = 0; k <= ORDER; k++) col[k] = W.ldD(k, slot);
 #pragma unroll
         for (int a = 0; a <= ORDER; a++) {
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k <= ORDER; k++) s += m[k][a] * col[k];
-            Dv[a * SLOTS + slot] = s;
+            W.stD(a, slot, s);
         }
     }
 }
@@ -184,7 +264,7 @@ __device__ __forceinline__ void change_D_init(double *ru, int lane)
 }
 
 template <int CPL>
-__device__ __forceinline__ void change_D(double *Dv, double *ru, int order, double factor, int lane)
+__device__ __forceinline__ void change_D(const WaveVecs<CPL> &W, double *ru, int order, double factor, int lane)
 {
     // R[i][j] = prod_{q=1..i} (q - 1 - factor j) / q on lanes 0..35 (cumprod of bdf.py compute_R), RU = R U on the
     // same lanes with all twelve operands read before the first multiply, then D[:order+1] = RU^T D[:order+1]
@@ -218,11 +298,11 @@ __device__ __forceinline__ void change_D(double *Dv, double *ru, int order, doub
     }
     __builtin_amdgcn_wave_barrier();
     switch (order) {
-        case 1: apply_RU<CPL, 1>(Dv, ru, lane); break;
-        case 2: apply_RU<CPL, 2>(Dv, ru, lane); break;
-        case 3: apply_RU<CPL, 3>(Dv, ru, lane); break;
-        case 4: apply_RU<CPL, 4>(Dv, ru, lane); break;
-        default: apply_RU<CPL, 5>(Dv, ru, lane); break;
+        case 1: apply_RU<CPL, 1>(W, ru, lane); break;
+        case 2: apply_RU<CPL, 2>(W, ru, lane); break;
+        case 3: apply_RU<CPL, 3>(W, ru, lane); break;
+        case 4: apply_RU<CPL, 4>(W, ru, lane); break;
+        default: apply_RU<CPL, 5>(W, ru, lane); break;
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -230,7 +310,7 @@ __device__ __forceinline__ void change_D(double *Dv, double *ru, int order, doub
 // bdf.py _step_impl after acceptance, for a compile-time order: D[order+2] = d - D[order+1]; D[order+1] = d;
 // D[k] += D[k+1] for k = order..0.  All rows are read before any is written (independent LDS reads).
 template <int CPL, int ORDER>
-__device__ __forceinline__ void accept_update(double *Dv, const double (&dd)[CPL], int lane, double (&d_ord)[CPL],
+__device__ __forceinline__ void accept_update(const WaveVecs<CPL> &W, const double (&dd)[CPL], int lane, double (&d_ord)[CPL],
                                               double (&d_ord2)[CPL])
 {
     constexpr int SLOTS = WAVE * CPL;
@@ -239,15 +319,15 @@ __device__ __forceinline__ void accept_update(double *Dv, const double (&dd)[CPL
         const int slot = c * WAVE + lane;
         double r[ORDER + 2];
 #pragma unroll
-        for (int k = 0; k <= ORDER + 1; k++) r[k] = Dv[k * SLOTS + slot];
+        for (int k = 0; k <= ORDER + 1; k++) r[k] = W.ldD(k, slot);
         const double top2 = dd[c] - r[ORDER + 1];
-        Dv[(ORDER + 2) * SLOTS + slot] = top2;
-        Dv[(ORDER + 1) * SLOTS + slot] = dd[c];
+        W.stD(ORDER + 2, slot, top2);
+        W.stD(ORDER + 1, slot, dd[c]);
         double acc = dd[c];
 #pragma unroll
         for (int k = ORDER; k >= 0; k--) {
             acc += r[k];
-            Dv[k * SLOTS + slot] = acc;
+            W.stD(k, slot, acc);
             if (k == ORDER) d_ord[c] = acc;
         }
         d_ord2[c] = top2;
@@ -255,7 +335,7 @@ __device__ __forceinline__ void accept_update(double *Dv, const double (&dd)[CPL
 }
 // predictor: y_predict = sum_k D[k], psi = sum_{k>=1} gamma_k D[k] / alpha_order
 template <int CPL, int ORDER>
-__device__ __forceinline__ void predict(const double *Dv, int lane, double inv_alpha, double (&yp)[CPL],
+__device__ __forceinline__ void predict(const WaveVecs<CPL> &W, int lane, double inv_alpha, double (&yp)[CPL],
                                         double (&psiv)[CPL])
 {
     constexpr int SLOTS = WAVE * CPL;
@@ -264,7 +344,7 @@ __device__ __forceinline__ void predict(const double *Dv, int lane, double inv_a
         const int slot = c * WAVE + lane;
         double r[ORDER + 1];
 #pragma unroll
-        for (int k = 0; k <= ORDER; k++) r[k] = Dv[k * SLOTS + slot];
+        for (int k = 0; k <= ORDER; k++) r[k] = W.ldD(k, slot);
         double sy = r[0], p = 0.0;
 #pragma unroll
         for (int k = 1; k <= ORDER; k++) {
@@ -423,7 +503,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB * SLOTS);     // group ids < 16: a byte each
     double *wave_base = reinterpret_cast<double *>(gtab + 4 * SLOTS);
     constexpr bool NZ_LDS = nz_in_lds(CPL);
-    constexpr int NVEC_K = nvec_of(CPL);
+    constexpr int NVEC_K = lds_vectors(CPL);
+    static_assert(WPB == WAVES_PER_BLOCK, "four waves per workgroup");
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
     // [0] next member of the chunk, [1] its end (-1: no chunk left), [2] point whose tables are in LDS, [3] the chunk's point
     volatile int *chunk_state = reinterpret_cast<volatile int *>(gtab + NGTAB * SLOTS);
@@ -456,7 +537,10 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     if (lane < 32) prof_lds[lane] = 0;
     int prof_slot = 31;
 #endif
-    double *Dv = V + V_D0 * SLOTS;
+    WaveVecs<CPL> W;
+    W.lds = V;
+    W.spill = (__attribute__((address_space(1))) double *)A.wave_spill +
+              ((size_t)blockIdx.x * WPB + wave) * ((size_t)spill_vectors(CPL) * SLOTS);
     change_D_init(ru, lane);
     const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
@@ -522,13 +606,37 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     }
     point = __builtin_amdgcn_readfirstlane(point);
     bool vnode[CPL];
-    int gs[CPL], gp[CPL], gn[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; c++) {
-        vnode[c] = lane * CPL + c < D;
-        gs[c] = gtab[G_SELF * SLOTS + c * WAVE + lane];
-        gp[c] = gtab[G_PREV * SLOTS + c * WAVE + lane];
-        gn[c] = gtab[G_NEXT * SLOTS + c * WAVE + lane];
+    for (int c = 0; c < CPL; c++) vnode[c] = lane * CPL + c < D;
+    // FD-Jacobian column groups of this lane's nodes and of their neighbours.  Up to CPL = 5 they sit in 3 CPL registers
+    // for the kernel's lifetime; deep columns (already spilling to scratch) read them from LDS at the top of each
+    // Jacobian phase instead (HC_GROUPS: a batch of byte loads through a pointer made opaque at that point, so that
+    // the loads are not hoisted back out of the loop).
+    // Which of the two is used where is decided by measurement and by bit-equality with the plain layout on Philox
+    // runs (tools/prof_depth.py prints a digest of the final state): group ids on demand for CPL 6-8 (+4..10 %),
+    // the row-start state in the global region for CPL 9-10 (+4 %).  Both together at CPL = 10 made hipcc 7.2 carry a
+    // stale value into the per-row failure count (tools/dev/dbg_failed.py) -- the combination is not used.
+    constexpr bool DEEP = CPL >= 6 && CPL <= 8;
+    constexpr bool DEEPY = CPL >= 9;
+    int gs_keep[CPL], gp_keep[CPL], gn_keep[CPL];
+    if (!DEEP) {
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            gs_keep[c] = gtab[G_SELF * SLOTS + c * WAVE + lane];
+            gp_keep[c] = gtab[G_PREV * SLOTS + c * WAVE + lane];
+            gn_keep[c] = gtab[G_NEXT * SLOTS + c * WAVE + lane];
+        }
+    }
+#define HC_GROUPS()                                                                          \
+    int gs[CPL], gp[CPL], gn[CPL];                                                           \
+    {                                                                                        \
+        auto gq = (const __attribute__((address_space(3))) signed char *)gtab;               \
+        if (DEEP) asm volatile("" : "+v"(gq));                                               \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) {                                    \
+            gs[c] = DEEP ? (int)gq[G_SELF * SLOTS + c * WAVE + lane] : gs_keep[c];           \
+            gp[c] = DEEP ? (int)gq[G_PREV * SLOTS + c * WAVE + lane] : gp_keep[c];           \
+            gn[c] = DEEP ? (int)gq[G_NEXT * SLOTS + c * WAVE + lane] : gn_keep[c];           \
+        }                                                                                    \
     }
     // state -> LDS
     double nscale = 1.0;
@@ -536,7 +644,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         const IoArgs io = load_const(A.io);
 #pragma unroll
         for (int c = 0; c < CPL; c++)
-            V[V_Y * SLOTS + c * WAVE + lane] = vnode[c] ? io.psi[member * D + lane * CPL + c] : 0.0;
+            W.template st<V_Y>(c * WAVE + lane, vnode[c] ? io.psi[member * D + lane * CPL + c] : 0.0);
         if (!A.host_noise) nscale = io.nscale[member];
     }
     int fresh_seen = 0;
@@ -593,15 +701,23 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             z = refresh ? z : z * nscale;
                         }
                     }
-                    V[V_NZ * SLOTS + c * WAVE + lane] = z;
+                    W.template st<V_NZ>(c * WAVE + lane, z);
                 }
                 nz_is_base = !refresh;
             }
             __builtin_amdgcn_wave_barrier();
             int failed = 0;
-            double yrow0[CPL];                   // every attempt restarts from the row's y0
+            // every attempt restarts from the row's y0: V_Y holds it when the row begins; a copy goes to the global
+            // region (fire-and-forget stores) for the rare retry of a deep column, instead of CPL register pairs held across
+            // the integrator
+            // (measured at CPL = 5: the register copy is 0.5 % faster, so it stays there)
+            double yrow0[DEEPY ? 1 : CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; c++) yrow0[c] = V[V_Y * SLOTS + c * WAVE + lane];
+            for (int c = 0; c < CPL; c++) {
+                const double y0c = W.template ld<V_Y>(c * WAVE + lane);
+                if (DEEPY) W.template st<V_Y0>(c * WAVE + lane, y0c);
+                else yrow0[DEEPY ? 0 : c] = y0c;
+            }
             // ---- up to 5 attempts (richards_pde.py:509-533)
             for (;;) {
                 attempts++;
@@ -615,7 +731,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     idx = (i < D - 1) ? idx : 0;
                     double z;
                     if (NZ_LDS) {
-                        z = V[V_NZ * SLOTS + (idx % CPL) * WAVE + idx / CPL];
+                        z = W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL);
                     } else {
                         // deep columns: no noise vector in LDS -- value of node idx for this attempt, read / generated
                         // again and damped in the order the in-place rule takes (x0.8 per failed attempt of this row)
@@ -642,10 +758,14 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 int redo_mask = 0, jac_stage = 0;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
-                    ycur[c] = yrow0[c];
-                    V[V_Y * SLOTS + c * WAVE + lane] = yrow0[c];   // sol.y[:, -1] before any accepted step
-                    Dv[0 * SLOTS + c * WAVE + lane] = ycur[c];
-                    V[V_FAC * SLOTS + c * WAVE + lane] = SQRT_EPS;
+                    // sol.y[:, -1] before any accepted step is y0 itself
+                    double y0c;
+                    if (DEEPY) y0c = attempts == 1 ? W.template ld<V_Y>(c * WAVE + lane) : W.template ld<V_Y0>(c * WAVE + lane);
+                    else y0c = yrow0[DEEPY ? 0 : c];
+                    ycur[c] = y0c;
+                    W.template st<V_Y>(c * WAVE + lane, y0c);
+                    W.stD(0, c * WAVE + lane, ycur[c]);
+                    W.template st<V_FAC>(c * WAVE + lane, SQRT_EPS);
                     yp[c] = psiv[c] = dd[c] = jl[c] = jd[c] = ju[c] = hj[c] = 0.0;
                     scl[c] = 1.0;
                 }
@@ -712,8 +832,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         for (int c = 0; c < CPL; c++) {
                             const int slot = c * WAVE + lane;
                             y0v[c] = ycur[c];
-                            Dv[1 * SLOTS + slot] = f[c];      // parked here until h_abs is known
-                            V[V_FP * SLOTS + slot] = f[c];    // base f of the first Jacobian
+                            W.stD(1, slot, f[c]);      // parked here until h_abs is known
+                            W.template st<V_FP>(slot, f[c]);    // base f of the first Jacobian
                             scl[c] = fast_div(1.0, ATOL + fabs(y0v[c]) * RTOL);
                         }
                         const double d0 = rms_ratio<CPL>(y0v, scl, lane, D, inv_sqrt_d);
@@ -735,7 +855,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         nfev++;
                         double df[CPL];
 #pragma unroll
-                        for (int c = 0; c < CPL; c++) df[c] = f[c] - V[V_FP * SLOTS + c * WAVE + lane];
+                        for (int c = 0; c < CPL; c++) df[c] = f[c] - W.template ld<V_FP>(c * WAVE + lane);
                         const double d1 = cc;
                         const double d2 = rms_ratio<CPL>(df, scl, lane, D, inv_sqrt_d) / h0;
                         double h1;
@@ -757,7 +877,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         nfev++;
                         if (newton_k == 0 && !current_jac) {   // f(y_predict): base value of a Jacobian refresh
 #pragma unroll
-                            for (int c = 0; c < CPL; c++) V[V_FP * SLOTS + c * WAVE + lane] = f[c];
+                            for (int c = 0; c < CPL; c++) W.template st<V_FP>(c * WAVE + lane, f[c]);
                         }
                         bool converged = false, failed_newton = false;
                         {
@@ -810,7 +930,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         HC_STAMP(C_NEWTON_FAIL);
                         if (current_jac) {
                             h_abs *= 0.5;
-                            change_D<CPL>(Dv, ru, order, 0.5, lane);
+                            change_D<CPL>(W, ru, order, 0.5, lane);
                             n_equal = 0;
                             have_lu = 0;
                             phase = C_STEP_TRY;
@@ -825,12 +945,13 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     if (phase == PH_JAC_REDO && have_f) {
                         have_f = false;
                         HC_STAMP(PH_JAC_REDO);
+                        HC_GROUPS();
                         // f = fun(y + h_new * [column small and in group g]); keep the new column where
                         // max_diff * scale_new < max_diff_new * scale  (common.py _sparse_num_jac)
                         __builtin_amdgcn_wave_barrier();
                         double fb[CPL];
 #pragma unroll
-                        for (int c = 0; c < CPL; c++) fb[c] = V[V_FP * SLOTS + c * WAVE + lane];
+                        for (int c = 0; c < CPL; c++) fb[c] = W.template ld<V_FP>(c * WAVE + lane);
                         const double fbU0 = shfl_up1(fb[CPL - 1], lane, 0.0), fbD0 = shfl_down1(fb[0], lane, 0.0);
                         const double fU0 = shfl_up1(f[CPL - 1], lane, 0.0), fD0 = shfl_down1(f[0], lane, 0.0);
                         const double fnU0 = shfl_up1(ju[CPL - 1], lane, 0.0), fnD0 = shfl_down1(jl[0], lane, 0.0);
@@ -855,12 +976,12 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             const bool u = mine && (md * sc2 < md2 * sc);
                             upd[c] = u ? 1.0 : 0.0;
                             if (u) {
-                                double fac = 10.0 * V[V_FAC * SLOTS + slot];
+                                double fac = 10.0 * W.template ld<V_FAC>(slot);
                                 const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
                                 hj[c] = (yp[c] + fac * ysc) - yp[c];
                                 if (md2 < NUM_JAC_DIFF_SMALL * sc2) fac *= 10.0;
                                 if (md2 > NUM_JAC_DIFF_BIG * sc2) fac *= 0.1;
-                                V[V_FAC * SLOTS + slot] = fmax(fac, NUM_JAC_MIN_FACTOR);
+                                W.template st<V_FAC>(slot, fmax(fac, NUM_JAC_MIN_FACTOR));
                                 flags |= 1 << (16 + c);
                             }
                         }
@@ -881,7 +1002,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             for (int c = 0; c < CPL; c++) {
                                 const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
                                 const bool done = (flags >> (16 + c)) & 1;   // an updated column already holds 10x its factor
-                                const double fac0 = V[V_FAC * SLOTS + c * WAVE + lane];
+                                const double fac0 = W.template ld<V_FAC>(c * WAVE + lane);
                                 const double hn = (yp[c] + 10.0 * fac0 * ysc) - yp[c];
                                 ycur[c] = yp[c] + ((((flags >> c) & 1) && !done && gs[c] == g) ? hn : 0.0);
                             }
@@ -891,20 +1012,21 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     }
                     if (phase == PH_JAC) {
                         HC_STAMP(PH_JAC);
+                        HC_GROUPS();
                         if (g < 0) {
                             // common.num_jac: step h per column from factor, f sign and |y|
 #pragma unroll
                             for (int c = 0; c < CPL; c++) {
                                 const int slot = c * WAVE + lane;
-                                const double fb = V[V_FP * SLOTS + slot];
-                                double fac = V[V_FAC * SLOTS + slot];
+                                const double fb = W.template ld<V_FP>(slot);
+                                double fac = W.template ld<V_FAC>(slot);
                                 const double ysc = (fb >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
                                 double h = (yp[c] + fac * ysc) - yp[c];
                                 for (int it = 0; it < 64 && vnode[c] && h == 0.0; it++) {
                                     fac *= 10.0;
                                     h = (yp[c] + fac * ysc) - yp[c];
                                 }
-                                V[V_FAC * SLOTS + slot] = fac;
+                                W.template st<V_FAC>(slot, fac);
                                 hj[c] = vnode[c] ? h : 1.0;
                             }
                             g = 0;
@@ -929,12 +1051,13 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     }
                     if (phase == C_JAC_FIN) {
                         HC_STAMP(C_JAC_FIN);
+                        HC_GROUPS();
                         // _sparse_num_jac: per-column max |diff| (rows j-1, j, j+1), its scale, factor update,
                         // J = diff / h.  jac_stage 0 = first look, 1 = after the retry pass below.
                         __builtin_amdgcn_wave_barrier();
                         double fb[CPL];
 #pragma unroll
-                        for (int c = 0; c < CPL; c++) fb[c] = V[V_FP * SLOTS + c * WAVE + lane];
+                        for (int c = 0; c < CPL; c++) fb[c] = W.template ld<V_FP>(c * WAVE + lane);
                         const double fbU0 = shfl_up1(fb[CPL - 1], lane, 0.0), fnU0 = shfl_up1(ju[CPL - 1], lane, 0.0);
                         const double fbD0 = shfl_down1(fb[0], lane, 0.0), fnD0 = shfl_down1(jl[0], lane, 0.0);
                         const double hU0 = shfl_up1(hj[CPL - 1], lane, 1.0), hD0 = shfl_down1(hj[0], lane, 1.0);
@@ -956,7 +1079,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             const bool small = vnode[c] && (md < A.jac_reject * sc);
                             small_bits |= small ? (1 << c) : 0;
                             my_groups |= small ? (1 << gs[c]) : 0;
-                            double fac = V[V_FAC * SLOTS + c * WAVE + lane];
+                            double fac = W.template ld<V_FAC>(c * WAVE + lane);
                             if (!((old_flags >> (16 + c)) & 1)) {
                                 if (md < NUM_JAC_DIFF_SMALL * sc) fac *= 10.0;
                                 if (md > NUM_JAC_DIFF_BIG * sc) fac *= 0.1;
@@ -985,7 +1108,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
 #pragma unroll
                             for (int c = 0; c < CPL; c++) {
                                 const double ysc = (fb[c] >= 0.0 ? 1.0 : -1.0) * fmax(ATOL, fabs(yp[c]));
-                                const double hn = (yp[c] + 10.0 * V[V_FAC * SLOTS + c * WAVE + lane] * ysc) - yp[c];
+                                const double hn = (yp[c] + 10.0 * W.template ld<V_FAC>(c * WAVE + lane) * ysc) - yp[c];
                                 ycur[c] = yp[c] + ((((small_bits >> c) & 1) && gs[c] == g) ? hn : 0.0);
                             }
                             phase = PH_JAC_REDO;
@@ -995,15 +1118,15 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                                 jl[c] = njl[c];
                                 jd[c] = njd[c];
                                 ju[c] = nju[c];
-                                if (vnode[c]) V[V_FAC * SLOTS + c * WAVE + lane] = nfac[c];
+                                if (vnode[c]) W.template st<V_FAC>(c * WAVE + lane, nfac[c]);
                             }
-                            jac_stage = 0;
+                                jac_stage = 0;
                             if (jac_init) {
                                 // rest of BDF.__init__: D[0] = y, D[1] = f0 * h_abs, order = 1
 #pragma unroll
                                 for (int c = 0; c < CPL; c++) {
                                     const int slot = c * WAVE + lane;
-                                    Dv[1 * SLOTS + slot] = Dv[1 * SLOTS + slot] * h_abs;
+                                    W.stD(1, slot, W.ldD(1, slot) * h_abs);
                                 }
                                 order = 1;
                                 n_equal = 0;
@@ -1030,7 +1153,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         if (error_norm > 1.0) {
                             const double factor = fmax(0.2, safety * exp_mid(-log_pos(error_norm) / (double)(order + 1)));
                             h_abs *= factor;
-                            change_D<CPL>(Dv, ru, order, factor, lane);
+                            change_D<CPL>(W, ru, order, factor, lane);
                             n_equal = 0;
                             phase = C_STEP_TRY;
                         } else {
@@ -1044,13 +1167,13 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         nsteps++;
                         double d_ord[CPL], d_ord2[CPL];          // updated D[order], D[order+2]
 #pragma unroll
-                        for (int c = 0; c < CPL; c++) V[V_Y * SLOTS + c * WAVE + lane] = ycur[c];   // sol.y[:, -1] so far
+                        for (int c = 0; c < CPL; c++) W.template st<V_Y>(c * WAVE + lane, ycur[c]);   // sol.y[:, -1] so far
                         switch (order) {
-                            case 1: accept_update<CPL, 1>(Dv, dd, lane, d_ord, d_ord2); break;
-                            case 2: accept_update<CPL, 2>(Dv, dd, lane, d_ord, d_ord2); break;
-                            case 3: accept_update<CPL, 3>(Dv, dd, lane, d_ord, d_ord2); break;
-                            case 4: accept_update<CPL, 4>(Dv, dd, lane, d_ord, d_ord2); break;
-                            default: accept_update<CPL, 5>(Dv, dd, lane, d_ord, d_ord2); break;
+                            case 1: accept_update<CPL, 1>(W, dd, lane, d_ord, d_ord2); break;
+                            case 2: accept_update<CPL, 2>(W, dd, lane, d_ord, d_ord2); break;
+                            case 3: accept_update<CPL, 3>(W, dd, lane, d_ord, d_ord2); break;
+                            case 4: accept_update<CPL, 4>(W, dd, lane, d_ord, d_ord2); break;
+                            default: accept_update<CPL, 5>(W, dd, lane, d_ord, d_ord2); break;
                         }
                         if (t == tf) {
                             phase = C_SUCCESS;
@@ -1082,7 +1205,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             order += best - 1;
                             const double factor = fmin(10.0, safety * fbest);
                             h_abs *= factor;
-                            change_D<CPL>(Dv, ru, order, factor, lane);
+                            change_D<CPL>(W, ru, order, factor, lane);
                             n_equal = 0;
                             have_lu = 0;
                             phase = C_STEP_BEGIN;
@@ -1098,7 +1221,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                                                      : __longlong_as_double(__double_as_longlong(t) + 1ll);
                         min_step = 10.0 * fabs(t_up - t);
                         if (h_abs < min_step) {
-                            change_D<CPL>(Dv, ru, order, min_step / h_abs, lane);
+                            change_D<CPL>(W, ru, order, min_step / h_abs, lane);
                             h_abs = min_step;
                             n_equal = 0;
                         }
@@ -1113,7 +1236,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             t_new = t + h_abs;
                             if (t_new - tf > 0.0) {
                                 t_new = tf;
-                                change_D<CPL>(Dv, ru, order, fabs(t_new - t) / h_abs, lane);
+                                change_D<CPL>(W, ru, order, fabs(t_new - t) / h_abs, lane);
                                 n_equal = 0;
                                 have_lu = 0;
                             }
@@ -1121,11 +1244,11 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                             h_abs = fabs(h);
                             const double inv_alpha = 1.0 / alpha_k(order);
                             switch (order) {
-                                case 1: predict<CPL, 1>(Dv, lane, inv_alpha, yp, psiv); break;
-                                case 2: predict<CPL, 2>(Dv, lane, inv_alpha, yp, psiv); break;
-                                case 3: predict<CPL, 3>(Dv, lane, inv_alpha, yp, psiv); break;
-                                case 4: predict<CPL, 4>(Dv, lane, inv_alpha, yp, psiv); break;
-                                default: predict<CPL, 5>(Dv, lane, inv_alpha, yp, psiv); break;
+                                case 1: predict<CPL, 1>(W, lane, inv_alpha, yp, psiv); break;
+                                case 2: predict<CPL, 2>(W, lane, inv_alpha, yp, psiv); break;
+                                case 3: predict<CPL, 3>(W, lane, inv_alpha, yp, psiv); break;
+                                case 4: predict<CPL, 4>(W, lane, inv_alpha, yp, psiv); break;
+                                default: predict<CPL, 5>(W, lane, inv_alpha, yp, psiv); break;
                             }
 #pragma unroll
                             for (int c = 0; c < CPL; c++) scl[c] = fast_div(1.0, ATOL + RTOL * fabs(yp[c]));
@@ -1165,7 +1288,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 failed++;
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
-                    if (NZ_LDS) V[V_NZ * SLOTS + c * WAVE + lane] *= 0.8;
+                    if (NZ_LDS) W.template st<V_NZ>(c * WAVE + lane, W.template ld<V_NZ>(c * WAVE + lane) * 0.8);
                 if (!refresh) nscale *= 0.8;
                 __builtin_amdgcn_wave_barrier();
                 if (attempts >= 5) break;
@@ -1174,7 +1297,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 double sq = 0.0;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
-                    const double dlt = V[V_Y * SLOTS + c * WAVE + lane] - yrow0[c];
+                    const double dlt = W.template ld<V_Y>(c * WAVE + lane) -
+                                       (DEEPY ? W.template ld<V_Y0>(c * WAVE + lane) : yrow0[DEEPY ? 0 : c]);
                     sq = fma(dlt, dlt, sq);
                 }
                 spin_mse = wave_sum(sq) / (double)D;
@@ -1190,7 +1314,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                         if (!vnode[c]) continue;
                         double z;
                         if (NZ_LDS) {
-                            z = V[V_NZ * SLOTS + c * WAVE + lane];
+                            z = W.template ld<V_NZ>(c * WAVE + lane);
                         } else {
                             z = io.base_noise[member * D + lane * CPL + c];
                             for (int k = 0; k < failed; k++) z *= 0.8;
@@ -1209,7 +1333,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         const double psi_sat_m = load_const(&A.P[point].psi_sat);
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-            yv[c] = V[V_Y * SLOTS + c * WAVE + lane];
+            yv[c] = W.template ld<V_Y>(c * WAVE + lane);
             unsat[c] = vnode[c] && !(yv[c] >= psi_sat_m);
         }
         const int istar = deepest_true<CPL>(unsat);
@@ -1250,7 +1374,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
         const IoArgs io = load_const(A.io);
 #pragma unroll
         for (int c = 0; c < CPL; c++)
-            if (vnode[c]) io.psi[member * D + lane * CPL + c] = V[V_Y * SLOTS + c * WAVE + lane];
+            if (vnode[c]) io.psi[member * D + lane * CPL + c] = W.template ld<V_Y>(c * WAVE + lane);
         if (!A.host_noise && lane == 0) io.nscale[member] = nscale;
 #ifdef HC_PROFILE
         __builtin_amdgcn_wave_barrier();

@@ -88,6 +88,7 @@ struct hc_handle {
     bool points_dirty = false;
     int chunk_members = 0;       // HYDROCOL_CHUNK_MEMBERS (0: derived from the member count)
     DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
+    DevBuf<double> wave_spill;   // per-wave vectors of deep columns that do not fit in LDS (hc_step.h WaveVecs)
     DevBuf<int> spin_iters;
     DevBuf<double> trace;        // diagnostic builds only
     int max_phase_iterations = MAX_PHASE_ITERATIONS;
@@ -234,31 +235,89 @@ __global__ void plugin_kernel(const ColumnDev P, int special, long long n_cells,
 // ------------------------------------------------------------------ launch dispatch
 namespace {
 
-// kernel launch through the per-CPL translation units (hc_launch.h)
-#ifdef HC_DEV_ONLY_CPL5
-#define HC_DISPATCH(FN, ...)                                        \
-    switch (h->cpl) {                                               \
-        case 3: err = FN<3>(__VA_ARGS__); break;                    \
-        case 5: err = FN<5>(__VA_ARGS__); break;                    \
-        default: return fail(HC_ERR_UNSUPPORTED, "development build: CPL 3 and 5 only"); \
-    }
-#else
-#define HC_DISPATCH(FN, ...)                                        \
-    switch (h->cpl) {                                               \
-        case 2: err = FN<2>(__VA_ARGS__); break;                    \
-        case 3: err = FN<3>(__VA_ARGS__); break;                    \
-        case 4: err = FN<4>(__VA_ARGS__); break;                    \
-        case 5: err = FN<5>(__VA_ARGS__); break;                    \
-        case 6: err = FN<6>(__VA_ARGS__); break;                    \
-        case 7: err = FN<7>(__VA_ARGS__); break;                    \
-        case 8: err = FN<8>(__VA_ARGS__); break;                    \
-        case 9: err = FN<9>(__VA_ARGS__); break;                    \
-        case 10: err = FN<10>(__VA_ARGS__); break;                  \
-        default:                                                    \
-            return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= %d", h->p.dim_d, \
-                        h->cpl, HC_MAX_DEPTH_NODES);                \
-    }
+// kernel launch through the per-CPL translation units (hc_launch.h).  HC_CPL_MASK (bit n = cells-per-lane count n is
+// linked in) lets development builds carry a few depths only.
+#ifndef HC_CPL_MASK
+#define HC_CPL_MASK 0x7FC
 #endif
+hipError_t launch_step_cpl_any(int cpl, bool &known, const LaunchCfg &cfg, const StepArgs &A)
+{
+    known = true;
+    switch (cpl) {
+#if (HC_CPL_MASK >> 2) & 1
+        case 2: return launch_step_cpl<2>(cfg, A);
+#endif
+#if (HC_CPL_MASK >> 3) & 1
+        case 3: return launch_step_cpl<3>(cfg, A);
+#endif
+#if (HC_CPL_MASK >> 4) & 1
+        case 4: return launch_step_cpl<4>(cfg, A);
+#endif
+#if (HC_CPL_MASK >> 5) & 1
+        case 5: return launch_step_cpl<5>(cfg, A);
+#endif
+#if (HC_CPL_MASK >> 6) & 1
+        case 6: return launch_step_cpl<6>(cfg, A);
+#endif
+#if (HC_CPL_MASK >> 7) & 1
+        case 7: return launch_step_cpl<7>(cfg, A);
+#endif
+#if (HC_CPL_MASK >> 8) & 1
+        case 8: return launch_step_cpl<8>(cfg, A);
+#endif
+#if (HC_CPL_MASK >> 9) & 1
+        case 9: return launch_step_cpl<9>(cfg, A);
+#endif
+#if (HC_CPL_MASK >> 10) & 1
+        case 10: return launch_step_cpl<10>(cfg, A);
+#endif
+        default: break;
+    }
+    known = false;
+    return hipSuccess;
+}
+hipError_t launch_rhs_cpl_any(int cpl, bool &known, const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt, double *aux)
+{
+    known = true;
+    switch (cpl) {
+#if (HC_CPL_MASK >> 2) & 1
+        case 2: return launch_rhs_cpl<2>(cfg, A, row, dydt, aux);
+#endif
+#if (HC_CPL_MASK >> 3) & 1
+        case 3: return launch_rhs_cpl<3>(cfg, A, row, dydt, aux);
+#endif
+#if (HC_CPL_MASK >> 4) & 1
+        case 4: return launch_rhs_cpl<4>(cfg, A, row, dydt, aux);
+#endif
+#if (HC_CPL_MASK >> 5) & 1
+        case 5: return launch_rhs_cpl<5>(cfg, A, row, dydt, aux);
+#endif
+#if (HC_CPL_MASK >> 6) & 1
+        case 6: return launch_rhs_cpl<6>(cfg, A, row, dydt, aux);
+#endif
+#if (HC_CPL_MASK >> 7) & 1
+        case 7: return launch_rhs_cpl<7>(cfg, A, row, dydt, aux);
+#endif
+#if (HC_CPL_MASK >> 8) & 1
+        case 8: return launch_rhs_cpl<8>(cfg, A, row, dydt, aux);
+#endif
+#if (HC_CPL_MASK >> 9) & 1
+        case 9: return launch_rhs_cpl<9>(cfg, A, row, dydt, aux);
+#endif
+#if (HC_CPL_MASK >> 10) & 1
+        case 10: return launch_rhs_cpl<10>(cfg, A, row, dydt, aux);
+#endif
+        default: break;
+    }
+    known = false;
+    return hipSuccess;
+}
+
+int unknown_depth(hc_handle *h)
+{
+    return fail(HC_ERR_UNSUPPORTED, "D = %d needs %d cells per lane; this build covers D <= %d (depth mask 0x%x)",
+                h->p.dim_d, h->cpl, HC_MAX_DEPTH_NODES, HC_CPL_MASK);
+}
 
 LaunchCfg launch_cfg(hc_handle *h, unsigned grid)
 {
@@ -276,8 +335,9 @@ int launch_step(hc_handle *h, const StepArgs &A)
     const long long want = (A.n_members + wpb - 1) / wpb;
     const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->n_cu);
     HIP_TRY(hipMemsetAsync(h->counters.p + 63, 0, sizeof(unsigned long long), h->stream));
-    hipError_t err = hipSuccess;
-    HC_DISPATCH(launch_step_cpl, launch_cfg(h, grid), A);
+    bool known = false;
+    const hipError_t err = launch_step_cpl_any(h->cpl, known, launch_cfg(h, grid), A);
+    if (!known) return unknown_depth(h);
     HIP_TRY(err);
     return HC_OK;
 }
@@ -286,8 +346,9 @@ int launch_rhs(hc_handle *h, const StepArgs &A, long long row, double *dydt, dou
 {
     const int wpb = wpb_of(h->cpl);
     const unsigned grid = (unsigned)((A.n_members + wpb - 1) / wpb);
-    hipError_t err = hipSuccess;
-    HC_DISPATCH(launch_rhs_cpl, launch_cfg(h, grid), A, row, dydt, aux);
+    bool known = false;
+    const hipError_t err = launch_rhs_cpl_any(h->cpl, known, launch_cfg(h, grid), A, row, dydt, aux);
+    if (!known) return unknown_depth(h);
     HIP_TRY(err);
     return HC_OK;
 }
@@ -335,6 +396,12 @@ int fill_args(hc_handle *h, StepArgs &A)
         A.chunk_members = (int)chunk;
         A.chunks_per_point = (int)((A.members_per_point + chunk - 1) / chunk);
         A.n_chunks = A.chunks_per_point * NP;
+    }
+    {
+        // deep columns: room for the per-wave vectors LDS cannot hold, for every wave of the persistent grid
+        const size_t cnt = (size_t)h->n_cu * WAVES_PER_BLOCK * spill_vectors(h->cpl) * (size_t)h->slots;
+        if (h->wave_spill.ensure(cnt)) return HC_ERR_DEVICE;
+        A.wave_spill = h->wave_spill.p;
     }
     A.P = h->Pdev.p;
     A.io = h->iodev.p;
@@ -431,6 +498,7 @@ int hc_destroy(hc_handle *h)
     h->tab.release(); h->node_tabs.release(); h->precip.release(); h->atm.release(); h->psi.release();
     h->base.release(); h->nscale.release(); h->fresh.release(); h->psi_rows.release(); h->scratch_d.release();
     h->diag.release();
+    h->wave_spill.release();
     h->spin_iters.release();
     h->trace.release();
     h->gtab.release(); h->wtd_obs.release(); h->draw_idx.release(); h->stats.release(); h->scratch_i.release();

@@ -194,3 +194,37 @@ def test_water_table_mean_includes_the_depth_of_the_first_node():
     assert np.allclose(mu1, mu0 + 30.0) and np.array_equal(sd0, sd1)
     both = moments_to_mean_std(np.stack([m, m]), 5.0, 30.0)
     assert both[0].shape == (2, 2) and np.allclose(both[0][1], mu1)
+
+
+@pytest.mark.parametrize("dim_d", [300, 361, 401, 461, 541, 581])
+def test_rows_in_one_launch_equal_rows_launched_one_by_one_with_philox_noise(gpu, dim_d):
+    """Row-to-row carried state (psi, the base noise and its damping, the failure count) must not depend on where the
+    launch boundaries fall, at every cells-per-lane count and with the in-kernel noise source.  Deep columns keep part
+    of that state in a per-wave global region and rebuild the noise per attempt; a build whose register allocation
+    went wrong at 10 cells per lane once passed every host-noise test and differed here from the second row on."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    cols = ColumnTables(params, synthetic_well(dim_d))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+    N, rows = 6, 50                                      # crosses the refresh row 48
+    rng = np.random.default_rng(dim_d)
+    y0 = np.tile(cols.z - 300.0, (N, 1)) + rng.standard_normal((N, cols.dim_d))
+    res = []
+    for step in (rows, 1, 7):
+        st = gpu.EnsembleStepper(cols, forcing, N)
+        st.set_state(y0)
+        st.set_noise_philox(77, 3)
+        wtd, stats = [], []
+        done = 0
+        while done < rows:
+            n = min(step, rows - done)
+            o = st.step_rows(1 + done, n, want_wtd=True, want_stats=True)
+            wtd.append(o["wtd"]); stats.append(o["stats"])
+            done += n
+        res.append((st.get_state(), np.concatenate(wtd), np.concatenate(stats), st.moments()))
+        st.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
+    assert np.isfinite(res[0][0]).all()

@@ -13,7 +13,7 @@ if "--cpl" in args:
     del args[i:i + 2]
 out = os.path.join(R, "tools", "dev", "_ab")
 os.makedirs(out, exist_ok=True)
-defines = tuple(args) + (("-DHC_DEV_ONLY_CPL5",) if set(cpls) <= {3, 5} else ())
+defines = tuple(args) + (f"-DHC_CPL_MASK={sum(1 << n for n in cpls)}",)
 lib = ge.build_library(os.path.join(out, f"lib_{name}.so"), cpls=cpls, defines=defines,
                        obj_dir=os.path.join(out, f"obj_{name}"), force=True)
 print(lib)
