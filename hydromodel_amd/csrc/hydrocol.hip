@@ -106,7 +106,7 @@ struct hc_handle {
     bool philox = false;
     uint64_t seed = 0;
     int64_t member_offset = 0;
-    int rows_per_launch = 48;
+    int rows_per_launch = 0;     // 0: chosen from the member count (auto_rows_per_launch)
     int n_cu = 256;
     double jac_reject = NUM_JAC_DIFF_REJECT;
 };
@@ -776,6 +776,14 @@ int hc_philox_normals(hc_handle *h, int64_t member, int64_t draw, double *out)
     return HC_OK;
 }
 
+// One simulated day per launch for large ensembles; small ones get proportionally longer launches, so that a launch
+// still holds ~64 k member-days of work and the tail behind its slowest wavefront stays small (include/hydrocol.h).
+static int auto_rows_per_launch(int64_t n_members)
+{
+    const int64_t days = std::max<int64_t>(1, std::min<int64_t>(65536 / std::max<int64_t>(n_members, 1), 365));
+    return (int)(48 * days);
+}
+
 int hc_step_rows(hc_handle *h, hc_step_args *a)
 {
     if (!h || !a) return fail(HC_ERR_ARG, "hc_step_rows: NULL argument");
@@ -798,7 +806,8 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
     a->launches = 0;
     int64_t fresh_consumed = 0;
     for (int64_t done = 0; done < a->n_rows;) {
-        const int chunk = (int)std::min<int64_t>(h->rows_per_launch, a->n_rows - done);
+        const int per_launch = h->rows_per_launch > 0 ? h->rows_per_launch : auto_rows_per_launch(N);
+        const int chunk = (int)std::min<int64_t>(per_launch, a->n_rows - done);
         const int64_t row0 = a->spinup ? a->row_begin : a->row_begin + done;
         int n_fresh = 0;
         if (!a->spinup)
@@ -989,6 +998,13 @@ int hc_set_generic_exponents(hc_handle *h, int32_t on)
 {
     if (!h) return fail(HC_ERR_ARG, "NULL handle");
     h->force_generic = on != 0;
+    return HC_OK;
+}
+
+int hc_set_rows_per_launch(hc_handle *h, int32_t rows)
+{
+    if (!h || rows < 0) return fail(HC_ERR_ARG, "hc_set_rows_per_launch: bad argument");
+    h->rows_per_launch = rows;
     return HC_OK;
 }
 

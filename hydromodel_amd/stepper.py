@@ -189,6 +189,10 @@ class EnsembleStepper:
         """Pin the generic-exponent cell model (include/hydrocol.h): same bits for a point alone or inside a sweep."""
         L.check(self.lib.hc_set_generic_exponents(self.h, int(bool(on))))
 
+    def set_rows_per_launch(self, rows):
+        """Rows per kernel launch (default 48); long launches suit small ensembles (include/hydrocol.h)."""
+        L.check(self.lib.hc_set_rows_per_launch(self.h, int(rows)))
+
     def set_iteration_budget(self, phase_steps):
         L.check(self.lib.hc_set_iteration_budget(self.h, int(phase_steps)))
 

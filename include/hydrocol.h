@@ -176,6 +176,15 @@ int hc_synchronize(hc_handle *h);
  * HYDROCOL_DEBUG_JAC_REJECT (raises num_jac's retry threshold), HYDROCOL_ROWS_PER_LAUNCH, HYDROCOL_CHUNK_MEMBERS
  * (members per scheduling chunk when several parameter points share a launch). */
 int hc_get_counters(hc_handle *h, uint64_t *out4);
+/* Rows one kernel launch of hc_step_rows covers; hc_step_rows splits longer requests.  Default (and rows = 0): 48 = one
+ * simulated day for ensembles of >= 65 536 members, proportionally more for smaller ones (48 x 65 536 / members, at
+ * most a year).
+ * A member's rows of a launch are solved back to back by one wavefront with psi resident in LDS, and a launch ends when
+ * its slowest wavefront does.  Large ensembles (>> 1 024 wavefronts' worth of members) balance within a day; a SMALL
+ * ensemble (a few members per wavefront, e.g. 4 096) loses ~15 % to that tail per launch and is better served by long
+ * launches (a year: the members' total costs are nearly equal).  Per-row device buffers grow with it
+ * (2 B x rows x members for the water-table indices). Results do not depend on it. */
+int hc_set_rows_per_launch(hc_handle *h, int32_t rows);
 /* Budget of one BDF attempt in trips of the kernel's phase loop (>= 1). */
 int hc_set_iteration_budget(hc_handle *h, int32_t phase_steps);
 

@@ -150,6 +150,7 @@ def test_single_row_matches_oracle(gpu, well):
     o = _oracle(cols, forcing)
     st = gpu.EnsembleStepper(cols, forcing, len(Y))
     same = total = 0
+    tiers = {"<1e-9": 0, "<1e-6": 0, "stiff <5e-2": 0}
     for row in (2, 24, 49):
         st.set_state(Y)
         st.set_noise_host(np.tile(n_rnd, (len(Y), 1)))
@@ -165,6 +166,7 @@ def test_single_row_matches_oracle(gpu, well):
             # bits of the FD Jacobian: held to 50x the integrator's own tolerance scale
             tol = 1e-6 if so["nfev"] <= 100 else 5e-2
             assert err < tol, (well, row, STATE_NAMES[k], err)
+            tiers["<1e-9" if err < 1e-9 else ("<1e-6" if err < 1e-6 else "stiff <5e-2")] += 1
             gs = out["stats"][0, k]
             total += 1
             same += [int(gs[0]), int(gs[1]), int(gs[2]), int(gs[3]), int(gs[4])] == \
@@ -172,7 +174,12 @@ def test_single_row_matches_oracle(gpu, well):
             if so["nfev"] <= 100:
                 assert int(out["wtd"][0, k]) == o.find_wtd(yo >= cols.soil.psi_sat)
             assert int(gs[5]) == nf
+    print(f"[well {well}] one-row solves vs the oracle: {same}/{total} with identical nfev/njev/nlu/steps/attempts; "
+          f"error tiers {tiers}")
     assert same >= 0.8 * total, (same, total)
+    # the loose tier is for the CONSTRUCTED stiff states (saturated top, lateral flow far from equilibrium: ~200 RHS
+    # evaluations); on rows of the reference's own trajectory it stays below 20 % (next-but-one test)
+    assert tiers["stiff <5e-2"] <= 0.5 * total, tiers
     st.close()
 
 
@@ -222,6 +229,11 @@ def test_reference_trajectory_rows_replay(gpu, well):
         same += out["stats"][0, 0, :3].tolist() == stats[i, :3].tolist()
     errs = np.array(errs)
     assert n_reg > 250
+    tiers = {"<1e-9": int((errs < 1e-9).sum()), "1e-9..1e-6": int(((errs >= 1e-9) & (errs < 1e-6)).sum()),
+             "1e-6..1e-2 (loose)": int((errs >= 1e-6).sum())}
+    print(f"[well {well}] {n_reg} rows of the reference's trajectory replayed: {same} with the reference's "
+          f"nfev/njev/nlu; error tiers {tiers}")
+    assert tiers["1e-6..1e-2 (loose)"] < 0.2 * n_reg, tiers
     assert same >= 0.95 * n_reg, (same, n_reg)
     assert np.median(errs) < 1e-8
     assert np.quantile(errs, 0.95) < 1e-5
@@ -513,8 +525,11 @@ def test_deep_reference_wells_match_oracle(gpu, dim_d):
     for k in range(N):
         r = o.run(forcing, Y[k], base[k], np.zeros((max(nf, 1), D)), 1, 1 + rows, want_stats=True)
         assert np.array_equal(out["wtd"][:, k], r["wtd_est"][1:1 + rows])
-        assert np.max(np.abs(y1[k] - r["psi"]) / (1 + np.abs(r["psi"]))) < 1e-3
-        assert (out["stats"][:, k, 0] == r["per_row"][1:1 + rows, 0]).mean() >= 0.7
+        err = np.max(np.abs(y1[k] - r["psi"]) / (1 + np.abs(r["psi"])))
+        frac = (out["stats"][:, k, 0] == r["per_row"][1:1 + rows, 0]).mean()
+        print(f"[D={dim_d}] member {k}: {rows} chained rows, final error {err:.1e}, rows with the oracle's nfev {frac:.0%}")
+        assert err < 1e-3
+        assert frac >= 0.7
     st.close()
 
 
