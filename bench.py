@@ -38,13 +38,14 @@ sys.path.insert(0, str(REPO))
 ROWS_PER_DAY = 48
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per member per 48-row launch at D=300, from rocprofv3 PMC passes on this launch shape
-# (profiles/r01_pmc_fetch_size_f.csv, r01_pmc_write_size_f.csv; N = 65 536): 2 x FETCH_SIZE (gfx950 counts
-# half of the fetched bytes -- confirmed on a calibration dispatch that only loads and stores psi)
-# + WRITE_SIZE = (2 x 80 754.1 + 183 726.8) KiB / 65 536 members.
-PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 = (2 * 80754.125 + 183726.8125) * 1024.0 / 65536.0
-# fp64 work per column-step at D=300 from rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 summed over the 31 launches of
-# this very bench (profiles/r01_pmc_sq_f64_bench_g.csv; wave instructions per column-step: 2 019.5 / 3 674.7 / 7 846.5 /
-# 685.3; x64 lanes, FMA = 2 flop) -- the secondary, honest roofline.  Days 2-3 alone need 8 % more (r01_pmc_sq_f64_f.csv).
+# (profiles/r02_pmc_fetch_size.csv, r02_pmc_write_size.csv; `tools/prof_traffic.py 65536`, dispatch 12; N = 65 536):
+# 2 x FETCH_SIZE (gfx950 counts half of the fetched bytes -- confirmed by dispatch 9 of the same run, a calibration
+# launch that only loads and stores psi: 153 600 KiB each way, FETCH_SIZE 78 024.5, WRITE_SIZE 154 624)
+# + WRITE_SIZE = (2 x 78 574.5 + 178 688) KiB / 65 536 members = 5.1 KiB.
+PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 = (2 * 78574.5 + 178688.0) * 1024.0 / 65536.0
+# fp64 work per column-step at D=300 from rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 summed over the 31 ensemble
+# launches of this very bench (profiles/r02_pmc_sq_f64_bench.csv; wave instructions per column-step: 2 019.5 / 3 674.7 /
+# 7 846.5 / 685.3 -- unchanged from round 1; x64 lanes, FMA = 2 flop) -- the secondary, honest roofline.
 PMC_F64_FLOP_PER_COLUMN_STEP_D300 = (2019.5 + 3674.7 + 685.3 + 2 * 7846.5) * 64.0
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
 
@@ -259,8 +260,8 @@ def main():
                      "traffic": (PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 * N
                                  if (D == 300 and abs(rows_per_launch - 48) < 1e-9) else None),
                      "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same launch shape "
-                                       "(profiles/r01_pmc_*_size_f.csv), scaled by members; psi stays in LDS for the "
-                                       "48 rows of a launch, so HBM sees ~1/44 of the algorithmic bytes",
+                                       "(profiles/r02_pmc_*_size.csv), scaled by members; psi stays in LDS for the "
+                                       "48 rows of a launch, so HBM sees ~1/45 of the algorithmic bytes",
                      "kernel": "hc::step_kernel", "launch_ms": launch_ms, "launches": sim.launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "path is fp64-VALU/recurrence bound (SURVEY.md §8d): ~24 RHS evaluations per "
