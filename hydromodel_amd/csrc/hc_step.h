@@ -718,6 +718,28 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 if (DEEPY) W.template st<V_Y0>(c * WAVE + lane, y0c);
                 else yrow0[DEEPY ? 0 : c] = y0c;
             }
+            // Deep columns have no noise vector in LDS: every lane keeps the values its own cells use (cell j reads
+            // n_rnd[max(j-1, 0)], the virtual top-node cell n_rnd[0]: SURVEY.md §8a8 quirk) in registers for the row, read or
+            // generated once here and damped in place after each failed attempt, as the reference damps its array.
+            double znow[NZ_LDS ? 1 : CPL];
+            if (!NZ_LDS) {
+                const IoArgs io = load_const(A.io);
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    const int i = lane * CPL + c;
+                    int idx = i >= 1 ? i - 1 : 0;
+                    idx = (i < D - 1) ? idx : 0;
+                    double z;
+                    if (A.host_noise) {
+                        z = refresh ? io.fresh[((size_t)fresh_seen * A.n_members + member) * D + idx]
+                                    : io.base_noise[member * D + idx];
+                    } else {
+                        z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), draw_row, (unsigned)idx);
+                        z = refresh ? z : z * nscale_row;
+                    }
+                    znow[NZ_LDS ? 0 : c] = z;
+                }
+            }
             // ---- up to 5 attempts (richards_pde.py:509-533)
             for (;;) {
                 attempts++;
@@ -729,22 +751,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     const int i = lane * CPL + c;
                     int idx = i >= 1 ? i - 1 : 0;
                     idx = (i < D - 1) ? idx : 0;
-                    double z;
-                    if (NZ_LDS) {
-                        z = W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL);
-                    } else {
-                        // deep columns: no noise vector in LDS -- value of node idx for this attempt, read / generated
-                        // again and damped in the order the in-place rule takes (x0.8 per failed attempt of this row)
-                        const IoArgs io = load_const(A.io);
-                        if (A.host_noise) {
-                            z = refresh ? io.fresh[((size_t)fresh_seen * A.n_members + member) * D + idx]
-                                        : io.base_noise[member * D + idx];
-                        } else {
-                            z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), draw_row, (unsigned)idx);
-                            z = refresh ? z : z * nscale_row;
-                        }
-                        for (int k = 0; k < failed; k++) z *= 0.8;
-                    }
+                    const double z = NZ_LDS ? W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL) : znow[NZ_LDS ? 0 : c];
                     rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * z;
                 }
                 // ================= one BDF integration over [t0, tf] =================
@@ -1287,8 +1294,10 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 // failed attempt: n_rnd *= 0.8 in place (richards_pde.py:522); restart from y0
                 failed++;
 #pragma unroll
-                for (int c = 0; c < CPL; c++)
+                for (int c = 0; c < CPL; c++) {
                     if (NZ_LDS) W.template st<V_NZ>(c * WAVE + lane, W.template ld<V_NZ>(c * WAVE + lane) * 0.8);
+                    else znow[NZ_LDS ? 0 : c] *= 0.8;
+                }
                 if (!refresh) nscale *= 0.8;
                 __builtin_amdgcn_wave_barrier();
                 if (attempts >= 5) break;

@@ -142,3 +142,18 @@ def test_synthetic_forcing_shape():
     assert 80.0 < precip.sum() / 2 < 170.0               # ~125 cm / yr
     assert np.all(wtd == -3.0)
     assert synthetic_well(300)["max_depth"] == 1495.0
+
+
+def test_wet_season_bit_and_skipped_rows():
+    """richards_pde.py:315: Oct-Mar of the rounded stamp is the wet season (PREDICT mode reads it); a row whose
+    observation is off the grid is skipped before anything is drawn (simulation.py:582-602), so it never refreshes."""
+    _, cols, forcing = digest(200)
+    g = golden("g1_tables_200.npz")
+    assert np.array_equal(forcing.wet_season.astype(bool), np.isin(g["month"], [10, 11, 12, 1, 2, 3]))
+    assert forcing.wet_season[0] == 1 and forcing.wet_season[-1] == 0          # the record runs Oct 1 -> Sep 30
+    assert set(np.unique(forcing.daylight | (forcing.wet_season << 1))) <= {0, 1, 2, 3}
+    assert not np.any(forcing.refresh[forcing.wtd_obs < 0])
+    from hydromodel_amd.stepper import column_params
+    p = column_params(cols, forcing.surface_evap)
+    assert p.flag_predict == 0 and p.sat_cells == int(cols.sat_cells) == 20
+    assert column_params(cols, forcing.surface_evap, {"PREDICT": True}).flag_predict == 1

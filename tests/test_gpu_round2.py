@@ -197,14 +197,20 @@ def test_water_table_mean_includes_the_depth_of_the_first_node():
 
 
 @pytest.mark.parametrize("dim_d", [300, 361, 401, 461, 541, 581])
-def test_rows_in_one_launch_equal_rows_launched_one_by_one_with_philox_noise(gpu, dim_d):
+@pytest.mark.parametrize("build", ["special", "generic", "predict"])
+def test_rows_in_one_launch_equal_rows_launched_one_by_one_with_philox_noise(gpu, dim_d, build):
     """Row-to-row carried state (psi, the base noise and its damping, the failure count) must not depend on where the
-    launch boundaries fall, at every cells-per-lane count and with the in-kernel noise source.  Deep columns keep part
-    of that state in a per-wave global region and rebuild the noise per attempt; a build whose register allocation
-    went wrong at 10 cells per lane once passed every host-noise test and differed here from the second row on."""
+    launch boundaries fall, at every cells-per-lane count, for every build of the kernel (specialised / generic
+    exponents / PREDICT) and with the in-kernel noise source.  Deep columns keep part of that state in a per-wave
+    global region and rebuild the noise per attempt; a build whose register allocation went wrong at 10 cells per lane
+    once passed every host-noise test and differed here from the second row on (DESIGN.md §5 "Deep columns")."""
     from hydromodel_amd.digest import ColumnTables, ForcingDigest
     from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    if build != "special" and dim_d in (361, 461, 541):
+        pytest.skip("generic / PREDICT builds: one depth per group of cells-per-lane variants")
     params = default_parameters()
+    if build == "predict":
+        params["Simulation_Flags"]["PREDICT"] = True
     cols = ColumnTables(params, synthetic_well(dim_d))
     forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
     N, rows = 6, 50                                      # crosses the refresh row 48
@@ -213,6 +219,8 @@ def test_rows_in_one_launch_equal_rows_launched_one_by_one_with_philox_noise(gpu
     res = []
     for step in (rows, 1, 7):
         st = gpu.EnsembleStepper(cols, forcing, N)
+        if build == "generic":
+            st.set_generic_exponents(True)
         st.set_state(y0)
         st.set_noise_philox(77, 3)
         wtd, stats = [], []
@@ -228,3 +236,36 @@ def test_rows_in_one_launch_equal_rows_launched_one_by_one_with_philox_noise(gpu
         for a, b in zip(res[0], other):
             assert np.array_equal(a, b)
     assert np.isfinite(res[0][0]).all()
+
+
+@pytest.mark.parametrize("dim_d", [401, 581])
+@pytest.mark.parametrize("build", ["generic", "predict"])
+def test_failure_accounting_of_the_other_builds_at_depth(gpu, dim_d, build):
+    """test_retry_rule_on_every_noise_layout for the generic-exponent and PREDICT kernels of the deep columns: three rows
+    in ONE launch, every attempt abandoned -> five failures per row and member, base noise x 0.8 fifteen times."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import pressure_head
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    if build == "predict":
+        params["Simulation_Flags"]["PREDICT"] = True
+    cols = ColumnTables(params, synthetic_well(dim_d))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+    y0, _ = pressure_head(cols, cols.por_raw)
+    N = 3
+    base = np.random.default_rng(4).standard_normal((N, cols.dim_d))
+    st = gpu.EnsembleStepper(cols, forcing, N)
+    if build == "generic":
+        st.set_generic_exponents(True)
+    st.set_iteration_budget(3)
+    st.set_state(y0)
+    st.set_noise_host(base)
+    out = st.step_rows(1, 3, fresh_noise=np.zeros((0,)), want_stats=True)
+    assert (out["stats"][:, :, 4] == 5).all() and (out["failed"] == 5).all()
+    c = st.counters()
+    assert c["failed_attempts"] == 3 * N * 5 and c["guard_trips"] == 3 * N * 5
+    expect = base.copy()
+    for _ in range(15):
+        expect = expect * 0.8
+    assert np.array_equal(st.get_noise_base(), expect)
+    st.close()
