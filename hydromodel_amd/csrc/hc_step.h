@@ -616,7 +616,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     // runs (tools/prof_depth.py prints a digest of the final state): group ids on demand for CPL 6-8 (+4..10 %),
     // the row-start state in the global region for CPL 9-10 (+4 %).  Both together at CPL = 10 made hipcc 7.2 carry a
     // stale value into the per-row failure count (tools/dev/dbg_failed.py) -- the combination is not used.
-    constexpr bool DEEP = CPL >= 6 && CPL <= 8;
+    constexpr bool DEEP = CPL >= 6 && CPL <= 8;   // (measured neutral at CPL = 5)
     constexpr bool DEEPY = CPL >= 9;
     int gs_keep[CPL], gp_keep[CPL], gn_keep[CPL];
     if (!DEEP) {

@@ -1,11 +1,12 @@
-"""Diagnostic build (-DHC_PROFILE -DHC_DEV_ONLY_CPL5): cycles per phase of the step kernel's state machine."""
+"""Diagnostic build (python tools/build_dev.py prof -DHC_PROFILE --cpl 5): cycles per phase of the step kernel's
+state machine.  python tools/prof_phases.py [tools/dev/_ab/lib_prof.so]"""
 import ctypes as C, os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 import numpy as np
-so = os.path.join(R, "gpurun_out_build", "libhydrocol_prof.so")
+so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "tools", "dev", "_ab", "lib_prof.so")
 from hydromodel_amd import _lib
-_lib.LIB_PATH = __import__("pathlib").Path(so)
+_lib.LIB_PATH = __import__("pathlib").Path(so).resolve()
 from helpers import digest, golden
 from hydromodel_amd.stepper import EnsembleStepper
 _, cols, forcing = digest(300)

@@ -1,4 +1,4 @@
-"""Diagnostic build (-DHC_PROFILE -DHC_DEV_ONLY_CPL5): time R back-to-back RHS evaluations per member at the
+"""Diagnostic build (python tools/build_dev.py prof -DHC_PROFILE --cpl 5): time R back-to-back RHS evaluations per member at the
 step kernel's occupancy.  python tools/prof_rhs_loop.py <lib.so> [N] [reps] [row]"""
 import os, sys, pathlib, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
