@@ -135,13 +135,17 @@ def cpu_baseline(cols, forcing, psi0, threads, seconds, first_row=1 + ROWS_PER_D
 
 def sustained_leg(cols, forcing, psi0, members, days, seed, device):
     """What the stepper sustains over a whole simulated year: `members` members through the first `days` days of the
-    same digest, one 48-row launch per day, with the failed-attempt and iteration-guard counters of the run."""
+    same digest, in 30-day requests that the library splits into launches of its own choosing, with the failed-attempt
+    and iteration-guard counters of the run."""
     from hydromodel_amd.ensemble import EnsembleSimulation
     days = min(days, (forcing.dim_t - 1) // ROWS_PER_DAY)
     sim = EnsembleSimulation(cols, forcing, members, seed=seed, device=device, psi0=psi0)
     t0 = time.perf_counter()
-    for _ in range(days):
-        sim.advance(ROWS_PER_DAY)
+    done = 0
+    while done < days:                       # 30-day requests; the library sizes its launches by the ensemble
+        n = min(30, days - done)             # (hc_set_rows_per_launch: 192 rows per launch at 16 384 members)
+        sim.advance(ROWS_PER_DAY * n)
+        done += n
     wall = time.perf_counter() - t0
     cnt = sim.stepper.counters()
     mean_cm, std_cm = sim.wtd_mean_std()

@@ -40,7 +40,7 @@ def test_bench_contract_one_rank():
     assert c["cores"] == c["host_cores_usable"] and abs(c["per_core"] * c["cores"] - c["value"]) < 1e-9 * c["value"]
     su = out["sustained"]
     assert su["unit"] == "column-days/s" and su["members"] == 2048 and su["days"] == 3 and su["value"] > 1e3
-    assert su["failed_attempts"] >= 0 and su["guard_trips"] >= 0 and su["launches"] == 3
+    assert su["failed_attempts"] >= 0 and su["guard_trips"] >= 0 and 1 <= su["launches"] <= 3
     assert out["value"] / c["value"] > 10            # a reported baseline, not a target -- but it must be the same unit
 
 
