@@ -11,6 +11,12 @@ unknown keys, only membership of the 12 is checked):
   run N stochastic members (in-kernel Philox noise, or the reference's NumPy streams with member 0 on
   ``SeedSequence(seed)`` and member k on ``spawn_key=(k,)``; one shared spin-up or one per member) and write the
   per-row water-table mean / sigma to ``<Output_Name>_ensemble.h5``.
+* ``"Ensemble": {..., "Points": [{"Soil_Properties": {"n": 1.7, "a0": 0.012}}, {...}, ...]}``: a parameter sweep
+  (BASELINE config 5) -- every entry is merged over the file's own sections to give one parameter point; all points run
+  with ``Members`` realisations each in ONE launch per batch of rows, each from its own spin-up, and the output holds
+  ``moments [P][3][T]``, ``wtd_mean_cm`` / ``wtd_std_cm [P][T]`` and ``initial_cond [P][D]``.
+* ``"Ensemble": {"repair_predict": true}`` with ``Simulation_Flags.PREDICT``: run the repaired predictive lateral flow
+   instead of raising the reference's ``TypeError``.
 """
 import sys
 from pathlib import Path
@@ -76,9 +82,13 @@ def _run_ensemble(params, water_data, output_name, ens, device):
     from .ensemble import EnsembleSimulation
     cols = ColumnTables(params, load_site_well(params))
     forcing = ForcingDigest(params, water_data, cols)
+    if cols.flags["PREDICT"] and not ens.get("repair_predict"):
+        raise TypeError("'numpy.float64' object cannot be interpreted as an integer")     # richards_pde.py:327-330
     n_members = int(ens.get("Members", 4096))
     days = int(ens.get("Days", (forcing.dim_t - 1) // 48))
     rows = min(days * 48, forcing.dim_t - 1)
+    if ens.get("Points"):
+        return _run_sweep(params, forcing, output_name, ens, n_members, rows, device)
     sim = EnsembleSimulation(cols, forcing, n_members, seed=int(ens.get("Seed", 0)), device=device,
                              noise=str(ens.get("Noise", "philox")).lower(),
                              spinup=str(ens.get("Spinup", "shared")).lower())
@@ -101,6 +111,38 @@ def _run_ensemble(params, water_data, output_name, ens, device):
         out = Path(stem + ".npz")
         np.savez_compressed(out, **arrays)
     print(f" Saving the ensemble water-table statistics to: {out}")
+    sim.close()
+
+
+def _run_sweep(params, forcing, output_name, ens, n_members, rows, device):
+    """Parameter points x members, one handle (ensemble.SweepSimulation)."""
+    import numpy as np
+    from . import hdf5io
+    from .digest import ColumnTables, load_site_well
+    from .ensemble import SweepSimulation, merge_parameters
+    from .stepper import moments_to_mean_std
+    well = load_site_well(params)
+    points = [ColumnTables(merge_parameters(params, ov), well) for ov in ens["Points"]]
+    sim = SweepSimulation(points, forcing, n_members, seed=int(ens.get("Seed", 0)), device=device)
+    done = 0
+    while done < rows:
+        n = min(48 * 30, rows - done)
+        sim.advance(n)
+        done += n
+        print(f" [Sweep {len(points)} points x{n_members}] {done} rows done")
+    moments = sim.moments()
+    mean_cm, std_cm = moments_to_mean_std(moments, points[0].dz, points[0].z[0])
+    arrays = dict(moments=moments, wtd_mean_cm=mean_cm, wtd_std_cm=std_cm, rows=np.array(rows),
+                  members=np.array(n_members), points=np.array(len(points)), initial_cond=sim.psi0,
+                  spinup_iterations=np.asarray(sim.spinup_iters))
+    stem = output_name.strip().replace(" ", "_") + "_ensemble"
+    if hdf5io.available():
+        out = Path(stem + ".h5")
+        hdf5io.write(out, arrays)
+    else:
+        out = Path(stem + ".npz")
+        np.savez_compressed(out, **arrays)
+    print(f" Saving the sweep's water-table statistics to: {out}")
     sim.close()
 
 

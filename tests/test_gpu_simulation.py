@@ -138,3 +138,30 @@ def test_cli_ensemble_numpy_streams_and_member_spinup(tmp_path, monkeypatch, cap
     assert np.array_equal(data["moments"][0, 1:49], np.full(48, 6))
     # member 0 spun up with the reference's own first draw: the reference's initial condition
     assert np.max(np.abs(data["initial_cond"][0] - golden("g5_traj_1.npz")["initial_cond"])) < 0.02
+
+
+def test_cli_parameter_sweep_block(tmp_path, monkeypatch, capsys):
+    """BASELINE config 5 from the reference's own command line: "Ensemble": {"Points": [...]}."""
+    from hydromodel_amd import cli
+    from hydromodel_amd.simulation import loadResults
+    params = default_parameters()
+    params["Site_Information"] = str(write_site_information(tmp_path / "site.json", {10: WELLS[200]}))
+    params["Data_Filename"] = str(write_forcing_csv(tmp_path / "forcing.csv", 1))
+    params["Ensemble"] = {"Members": 64, "Seed": 3, "Days": 2,
+                          "Points": [{}, {"Soil_Properties": {"n": 1.7, "a0": 0.012}},
+                                     {"Soil_Properties": {"psi_sat": -0.5}, "Hydraulic_Conductivity": {"Sigma_Noise": 1.0}}]}
+    (tmp_path / "p.json").write_text(json.dumps(params))
+    monkeypatch.chdir(tmp_path)
+    cli.run_cli(["berkeley_hydro_main.py", "--params", str(tmp_path / "p.json")])
+    data = loadResults(tmp_path / "Sim_00_ensemble.h5")
+    assert int(data["points"]) == 3 and int(data["members"]) == 64 and int(data["rows"]) == 96
+    assert data["moments"].shape == (3, 3, 17520) and data["initial_cond"].shape == (3, 200)
+    assert np.array_equal(data["moments"][:, 0, 1:97], np.full((3, 96), 64))
+    assert np.all(np.isfinite(data["wtd_mean_cm"][:, 1:97])) and np.all(data["spinup_iterations"] > 0)
+    assert not np.array_equal(data["initial_cond"][0], data["initial_cond"][1])
+    # PREDICT from the command line keeps the reference's error unless the repair is requested
+    params["Simulation_Flags"]["PREDICT"] = True
+    (tmp_path / "q.json").write_text(json.dumps(params))
+    with pytest.raises(SystemExit):
+        cli.run_cli(["berkeley_hydro_main.py", "--params", str(tmp_path / "q.json")])
+    assert "cannot be interpreted as an integer" in capsys.readouterr().out
