@@ -520,10 +520,16 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     HC_V(OUT[c] = ldexp(_b[c], (int)_dk[c]))
 
 // The cell model for arbitrary exponents (n > 1, lambda > 0; both plugins), vertical like model_cells_special.
-// Every power x^y is exp(y log x) on the in-house kernels above, with one log per distinct base (alpha|psi|, the
-// van Genuchten denominator, S_e); x = 0 is patched to the limit 0 (all exponents here are positive).  Against
-// libm's pow the result differs by |y log x| * 2^-53 ~ a few 1e-15 relative, two decades inside the 1e-11 parity
-// tier of theta, C and K; libm's pow costs ~3.6x the whole column-step.
+// Every power x^y is exp(y log x) on the in-house kernels above, with one log per distinct base; x = 0 is patched to
+// the limit 0 (all exponents here are positive).  Against libm's pow the result differs by |y log x| * 2^-53 ~ a few
+// 1e-15 relative, two decades inside the 1e-11 parity tier of theta, C and K; libm's pow costs ~3.6x the whole column-step.
+// Two logs / exps fewer per cell than the literal form (round 2), by algebra that stays inside those tiers:
+//   * (alpha|psi|)^(n-1) = (alpha|psi|)^n / (alpha|psi|): a division instead of a second exp of the same log;
+//   * powers of S_e: an unsaturated cell has S_e = (1 + (alpha|psi|)^n)^-m up to the rounding of the reference's
+//     theta_res + delta * pfac - theta_res round trip, so log S_e = -m log(1 + (alpha|psi|)^n) (already at hand),
+//     S_e^(1/m + 1) = pfac / (1 + (alpha|psi|)^n) and S_e^(1/m) = 1 / (1 + (alpha|psi|)^n).  Where that round trip's
+//     cancellation noise is not negligible (very dry cells, S_e < ~1e-3) C is below epsilon and clamped to it on both
+//     sides, and K enters with an absolute tolerance; saturated cells (S_e = 1) take C = epsilon, K = K_bkg anyway.
 template <int N, int SLOTS>
 __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const double *tab, int slot0,
                                                     const double *psi, const double *rnd, double *theta, double *K,
@@ -532,7 +538,7 @@ __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const do
     double _a[N], _b[N], _d[N], _e[N], _g[N], _h[N], _z[N], _w[N], _t1[N], _t2[N], _dk[N];
     bool _lo[N];
     int _ex[N];
-    double por[N], delta[N], ap[N], Lap[N], apn[N], x[N], s[N], Ls[N], y[N], u[N];
+    double por[N], delta[N], ap[N], Lap[N], apn[N], q1[N], Lq[N], x[N], s[N], y[N], u[N];
     bool sat[N], apz[N], sz[N];
     HC_V(por[c] = tab[T_POR * SLOTS + slot0 + c * WAVE])
     HC_V(delta[c] = por[c] - P.theta_res)
@@ -545,9 +551,9 @@ __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const do
     HC_V(y[c] = P.n * Lap[c])
     HC_VEXP(apn, y)
     HC_V(apn[c] = apz[c] ? 0.0 : apn[c])
-    HC_V(x[c] = 1.0 + apn[c])
-    HC_VLOG(u, x)
-    HC_V(y[c] = -P.m * u[c])
+    HC_V(q1[c] = 1.0 + apn[c])
+    HC_VLOG(Lq, q1)
+    HC_V(y[c] = -P.m * Lq[c])
     HC_VEXP(u, y)
     HC_V(pfac[c] = u[c])
     HC_V(y[c] = fma(delta[c], pfac[c], P.theta_res))
@@ -564,15 +570,19 @@ __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const do
     HC_V(s[c] = fma(_e[c], _b[c], _d[c]))
     HC_V(s[c] = fmin(fmax(s[c], 0.0), 1.0))
     HC_V(sz[c] = s[c] == 0.0)
-    HC_V(x[c] = sz[c] ? 1.0 : s[c])
-    HC_VLOG(Ls, x)
+    // 1 / (1 + (alpha|psi|)^n) = S_e^(1/m) of an unsaturated cell
+    HC_V(_b[c] = __builtin_amdgcn_rcp(q1[c]))
+    HC_V(_d[c] = fma(-q1[c], _b[c], 1.0))
+    HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))
+    HC_V(_d[c] = fma(-q1[c], _b[c], 1.0))
+    HC_V(x[c] = fma(_d[c], _b[c], _b[c]))                // x = 1 / q1
     if (P.model == 0) {
         // K_bkg = exp(log m - Lt/2 + sqrt(Lt) eps), Lt = log(1 + sigma (1 - S_e) / m^2); K = S_e^lambda K_bkg
-        double invm2[N], logm[N], noisec[N], Lt[N];
+        double invm2[N], logm[N], noisec[N], Lt[N], t[N];
         HC_V(invm2[c] = tab[T_INVM2 * SLOTS + slot0 + c * WAVE])
         HC_V(y[c] = P.sigma * (1.0 - s[c]))
-        HC_V(x[c] = fma(y[c], invm2[c], 1.0))
-        HC_VLOG(Lt, x)
+        HC_V(t[c] = fma(y[c], invm2[c], 1.0))
+        HC_VLOG(Lt, t)
         HC_V(logm[c] = tab[T_LOGM * SLOTS + slot0 + c * WAVE])
         HC_V(noisec[c] = tab[T_NOISEC * SLOTS + slot0 + c * WAVE])
         HC_V(u[c] = sqrt_pos(Lt[c]))
@@ -582,7 +592,7 @@ __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const do
         if (P.lambda == 1.0) {
             HC_V(u[c] = s[c])
         } else {
-            HC_V(y[c] = P.lambda * Ls[c])
+            HC_V(y[c] = sat[c] ? 0.0 : -(P.lambda * P.m) * Lq[c])
             HC_VEXP(u, y)
             HC_V(u[c] = sz[c] ? 0.0 : u[c])
         }
@@ -590,21 +600,19 @@ __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const do
         HC_V(K[c] = sat[c] ? kbo[c] : y[c])
     } else {
         // vanGenuchten.py:91-98: K = K_sat sqrt(S_e) (1 - (1 - S_e^(1/m))^m)^n, capped at K_sat
-        double mth[N], v[N];
+        double mth[N], v[N], t[N];
         bool vz[N];
-        HC_V(y[c] = P.inv_m * Ls[c])
-        HC_VEXP(mth, y)
-        HC_V(mth[c] = sz[c] ? 0.0 : mth[c])
+        HC_V(mth[c] = sz[c] ? 0.0 : (sat[c] ? 1.0 : x[c]))
         HC_V(v[c] = 1.0 - mth[c])
         HC_V(vz[c] = !(v[c] > 0.0))
-        HC_V(x[c] = vz[c] ? 1.0 : v[c])
-        HC_VLOG(u, x)
+        HC_V(t[c] = vz[c] ? 1.0 : v[c])
+        HC_VLOG(u, t)
         HC_V(y[c] = P.m * u[c])
         HC_VEXP(u, y)
         HC_V(v[c] = 1.0 - (vz[c] ? 0.0 : u[c]))
         HC_V(vz[c] = !(v[c] > 0.0))
-        HC_V(x[c] = vz[c] ? 1.0 : v[c])
-        HC_VLOG(u, x)
+        HC_V(t[c] = vz[c] ? 1.0 : v[c])
+        HC_VLOG(u, t)
         HC_V(y[c] = P.n * u[c])
         HC_VEXP(u, y)
         HC_V(u[c] = vz[c] ? 0.0 : u[c])
@@ -612,13 +620,17 @@ __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const do
         HC_V(y[c] = fmin(P.sat_soil * sqrt_pos(s[c]) * u[c], P.sat_soil))
         HC_V(K[c] = sat[c] ? kbo[c] : y[c])
     }
-    // C = m n alpha delta S_e^(1/m + 1) (alpha|psi|)^(n-1)
-    HC_V(y[c] = (P.inv_m + 1.0) * Ls[c])
-    HC_VEXP(u, y)
-    HC_V(u[c] = sz[c] ? 0.0 : u[c])
-    HC_V(y[c] = (P.n - 1.0) * Lap[c])
-    HC_VEXP(x, y)
-    HC_V(x[c] = apz[c] ? 0.0 : x[c])
+    // C = m n alpha delta S_e^(1/m + 1) (alpha|psi|)^(n-1) = m n alpha delta (pfac / q1) ((alpha|psi|)^n / (alpha|psi|))
+    HC_V(u[c] = sz[c] ? 0.0 : pfac[c] * x[c])
+    HC_V(_b[c] = __builtin_amdgcn_rcp(apz[c] ? 1.0 : ap[c]))
+    HC_V(_a[c] = apz[c] ? 1.0 : ap[c])
+    HC_V(_d[c] = fma(-_a[c], _b[c], 1.0))
+    HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))
+    HC_V(_d[c] = fma(-_a[c], _b[c], 1.0))
+    HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))
+    HC_V(_d[c] = apn[c] * _b[c])
+    HC_V(_e[c] = fma(-_a[c], _d[c], apn[c]))
+    HC_V(x[c] = fma(_e[c], _b[c], _d[c]))                // apn / ap  (apn = 0 where ap = 0)
     HC_V(y[c] = P.mn_alpha * delta[c] * u[c] * x[c])
     HC_V(C[c] = (int(!sat[c]) & int(y[c] >= P.epsilon) & int(y[c] < INFINITY)) ? y[c] : P.epsilon)
 }

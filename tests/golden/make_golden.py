@@ -13,6 +13,7 @@ Usage:
     python tests/golden/make_golden.py traj 101   # G5 trajectory, well 1 (D=101), ~8 min
     python tests/golden/make_golden.py traj 200   # G5 trajectory, synthetic D=200, ~8 min
     python tests/golden/make_golden.py points     # G1-G4 at three non-default (a0, psi_sat, lambda, sigma) points, ~1 min
+    python tests/golden/make_golden.py points_short  # first 240 rows of year-long runs at two of those points, ~1 min
     python tests/golden/make_golden.py short      # first days of vanGenuchten / HLIFT / ET+LF-off runs, ~1 min
 
 Vector families:
@@ -415,9 +416,9 @@ class _StopRun(Exception):
     pass
 
 
-def g5_short(well_no, tmp, n_rows, model="vrettas_fung", flags=None):
+def g5_short(well_no, tmp, n_rows, model="vrettas_fung", flags=None, overrides=None):
     """First n_rows rows of the year-long run (whole-year forcing file, run() interrupted): per-row input/output."""
-    sim, params, data = _setup(well_no, tmp, model=model, flags=flags)
+    sim, params, data = _setup(well_no, tmp, model=model, flags=flags, overrides=overrides)
     m = sim.mData
     pde = sim.pde_model
     cls = type(pde)
@@ -482,6 +483,10 @@ def main(argv):
                 _save(f"g1p_tables_{tag}.npz", g1_tables(sim))
                 _save(f"g2p_pointwise_{tag}.npz", g2_pointwise(sim))
                 _save(f"g34p_states_{tag}.npz", g34_states(sim))
+        elif mode == "points_short":
+            # first 240 rows of year-long reference runs at two non-default points (lambda != 1: generic-exponent path)
+            for tag in ("a03l13", "s07l08"):
+                _save(f"g5sp_{tag}_200.npz", g5_short(200, tmp, 240, overrides=POINTS[tag]))
         elif mode == "traj":
             well = int(argv[2])
             _save(f"g5_traj_{well}.npz", g5_trajectory(well, tmp))

@@ -131,3 +131,30 @@ def test_two_days_at_the_point_match_the_oracle(gpu, tag):
         equal += int((out["wtd"][:, k] == ref["wtd_est"][1:1 + rows]).sum())
         total += rows
     assert equal >= 0.98 * total, (equal, total)
+
+
+@pytest.mark.parametrize("tag", ["a03l13", "s07l08"])
+def test_first_days_of_the_reference_run_at_the_point_replay_on_the_gpu(gpu, tag):
+    """240 rows recorded inside the reference's own year-long run at the point (lambda != 1: the generic-exponent kernel),
+    each replayed from the reference's input state and noise vector."""
+    _, cols, forcing = digest_point(tag)
+    g = golden(f"g5sp_{tag}_200.npz")
+    st = gpu.EnsembleStepper(cols, forcing, 1)
+    errs, same = [], 0
+    for k, i in enumerate(g["rows"]):
+        st.set_state(g["y0"][k][None, :])
+        st.set_noise_host(g["nrnd_in"][k][None, :])
+        fresh = g["nrnd_in"][k][None, None, :] if forcing.refresh[i] else np.zeros((0,))
+        out = st.step_rows(int(i), 1, fresh_noise=fresh, want_stats=True)
+        y1 = st.get_state()[0]
+        ref = g["y1"][k]
+        errs.append(np.max(np.abs(y1 - ref) / (1 + np.abs(ref))))
+        same += out["stats"][0, 0, :5].tolist() == g["stats"][k].tolist()
+    st.close()
+    errs = np.array(errs)
+    tiers = {"<1e-9": int((errs < 1e-9).sum()), "1e-9..1e-6": int(((errs >= 1e-9) & (errs < 1e-6)).sum()),
+             ">=1e-6 (loose)": int((errs >= 1e-6).sum())}
+    print(f"[{tag}] 240 reference rows on the GPU: {same} with the reference's nfev/njev/nlu/steps/attempts; tiers {tiers}")
+    assert same >= 0.85 * len(errs), (same, len(errs))
+    assert tiers[">=1e-6 (loose)"] < 0.2 * len(errs), tiers
+    assert np.median(errs) < 1e-8 and errs.max() < 5e-2

@@ -111,6 +111,28 @@ def test_single_row_solve_at_the_point_matches_the_reference(tag):
     assert total >= 12 and same == total, (same, total)
 
 
+@pytest.mark.parametrize("tag", ["a03l13", "s07l08"])
+def test_first_days_of_the_reference_run_at_the_point_replay(tag):
+    """First 240 rows of the reference's own year-long run at the point (lambda != 1), replayed row by row."""
+    _, cols, forcing = digest_point(tag)
+    o = Oracle(cols, forcing.surface_evap)
+    g = golden(f"g5sp_{tag}_200.npz")
+    assert g["rows"].tolist() == list(range(1, 241))
+    errs, same = [], 0
+    for k, i in enumerate(g["rows"]):
+        row = Oracle.row(forcing.precip[i], forcing.atm[i], forcing.daylight[i], forcing.wtd_obs[i])
+        y1, st, n_out, _ = o.solve_row(row, i - 1, i, g["y0"][k], g["nrnd_in"][k])
+        ref = g["y1"][k]
+        errs.append(np.max(np.abs(y1 - ref) / (1.0 + np.abs(ref))))
+        same += [st["nfev"], st["njev"], st["nlu"], st["nsteps"], st["attempts"]] == g["stats"][k].tolist()
+        assert np.array_equal(n_out, g["nrnd_out"][k])
+    errs = np.array(errs)
+    print(f"[{tag}] 240 reference rows: {same} with identical nfev/njev/nlu/steps/attempts, median error {np.median(errs):.1e}, "
+          f"max {errs.max():.1e}")
+    assert same >= 0.9 * len(errs), (same, len(errs))
+    assert np.median(errs) < 1e-10 and np.quantile(errs, 0.9) < 1e-5 and errs.max() < 5e-2
+
+
 # ------------------------------------------------------------------------------- the n axis
 @pytest.mark.parametrize("n", [1.5, 1.7, 2.5, 3.0])
 def test_exponents_the_reference_cannot_run_use_the_modulus_form(n):
