@@ -48,7 +48,9 @@ constexpr int LDS_BYTES = 160 * 1024;
 // factors (read and written by Jacobian evaluations only, ~1.2 per row), D[6], the Jacobian's base f and the accepted
 // state (both written once per step or accepted step -- fire-and-forget stores -- and read once per Jacobian / row),
 // then D[5], D[4].  Every lane only ever touches its own slots of these, so program order is all the ordering needed.
-// The noise vector is read across lanes (cell j uses n_rnd[j-1]): it is either in LDS (CPL <= 6) or rebuilt per attempt.
+// The noise vector is read across lanes (cell j uses n_rnd[j-1]) and at every attempt: it is always in LDS.  (Round 1
+// dropped it from LDS for deep columns and rebuilt it per attempt; with the overflow region in place keeping it is
+// faster at every depth -- D = 401 +3 %, 541 +6 %, 581 +8 % -- and removes a second code path.)
 __host__ __device__ constexpr int lds_vectors(int cpl)      // how many of the twelve fit, four waves per workgroup
 {
     const int slots = 64 * cpl;
@@ -56,10 +58,9 @@ __host__ __device__ constexpr int lds_vectors(int cpl)      // how many of the t
     const int n = ((LDS_BYTES - tables) / WAVES_PER_BLOCK - WAVE_SCRATCH * 8) / (slots * 8);
     return n < NVEC ? n : NVEC;
 }
-__host__ __device__ constexpr bool nz_in_lds(int cpl) { return cpl <= 6; }
 __host__ __device__ constexpr int lds_listed(int cpl)       // ... of the eleven vectors other than the noise
 {
-    const int n = lds_vectors(cpl) - (nz_in_lds(cpl) ? 1 : 0);
+    const int n = lds_vectors(cpl) - 1;
     return n < NVEC - 1 ? n : NVEC - 1;
 }
 __host__ __device__ constexpr int spill_vectors(int cpl) { return NVEC - lds_listed(cpl); }   // incl. V_Y0
@@ -502,7 +503,6 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
     double *tab = lds;
     signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB * SLOTS);     // group ids < 16: a byte each
     double *wave_base = reinterpret_cast<double *>(gtab + 4 * SLOTS);
-    constexpr bool NZ_LDS = nz_in_lds(CPL);
     constexpr int NVEC_K = lds_vectors(CPL);
     static_assert(WPB == WAVES_PER_BLOCK, "four waves per workgroup");
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
@@ -682,8 +682,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 const IoArgs io = load_const(A.io);
                 draw_row = A.spinup ? PHILOX_DRAW_SPINUP : ((refresh && !A.host_noise) ? (unsigned)io.draw_idx[row] : 0u);
             }
-            const double nscale_row = nscale;      // damping of the base vector when the row starts
-            if (NZ_LDS && (refresh || !nz_is_base)) {
+            if (refresh || !nz_is_base) {
                 const IoArgs io = load_const(A.io);
                 // Philox draws mirror the reference's order (simulation.py:426,561,601): the spin-up vector has
                 // its own index, 0 is the base vector, refresh row k uses draw k >= 1
@@ -718,28 +717,6 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 if (DEEPY) W.template st<V_Y0>(c * WAVE + lane, y0c);
                 else yrow0[DEEPY ? 0 : c] = y0c;
             }
-            // Deep columns have no noise vector in LDS: every lane keeps the values its own cells use (cell j reads
-            // n_rnd[max(j-1, 0)], the virtual top-node cell n_rnd[0]: SURVEY.md §8a8 quirk) in registers for the row, read or
-            // generated once here and damped in place after each failed attempt, as the reference damps its array.
-            double znow[NZ_LDS ? 1 : CPL];
-            if (!NZ_LDS) {
-                const IoArgs io = load_const(A.io);
-#pragma unroll
-                for (int c = 0; c < CPL; c++) {
-                    const int i = lane * CPL + c;
-                    int idx = i >= 1 ? i - 1 : 0;
-                    idx = (i < D - 1) ? idx : 0;
-                    double z;
-                    if (A.host_noise) {
-                        z = refresh ? io.fresh[((size_t)fresh_seen * A.n_members + member) * D + idx]
-                                    : io.base_noise[member * D + idx];
-                    } else {
-                        z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), draw_row, (unsigned)idx);
-                        z = refresh ? z : z * nscale_row;
-                    }
-                    znow[NZ_LDS ? 0 : c] = z;
-                }
-            }
             // ---- up to 5 attempts (richards_pde.py:509-533)
             for (;;) {
                 attempts++;
@@ -751,7 +728,7 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                     const int i = lane * CPL + c;
                     int idx = i >= 1 ? i - 1 : 0;
                     idx = (i < D - 1) ? idx : 0;
-                    const double z = NZ_LDS ? W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL) : znow[NZ_LDS ? 0 : c];
+                    const double z = W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL);
                     rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * z;
                 }
                 // ================= one BDF integration over [t0, tf] =================
@@ -1294,10 +1271,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 // failed attempt: n_rnd *= 0.8 in place (richards_pde.py:522); restart from y0
                 failed++;
 #pragma unroll
-                for (int c = 0; c < CPL; c++) {
-                    if (NZ_LDS) W.template st<V_NZ>(c * WAVE + lane, W.template ld<V_NZ>(c * WAVE + lane) * 0.8);
-                    else znow[NZ_LDS ? 0 : c] *= 0.8;
-                }
+                for (int c = 0; c < CPL; c++)
+                    W.template st<V_NZ>(c * WAVE + lane, W.template ld<V_NZ>(c * WAVE + lane) * 0.8);
                 if (!refresh) nscale *= 0.8;
                 __builtin_amdgcn_wave_barrier();
                 if (attempts >= 5) break;
@@ -1319,18 +1294,8 @@ __global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
                 if (lane == 0) atomicAdd(&io.counters[1], (unsigned long long)failed);
                 if (!refresh && A.host_noise) {
 #pragma unroll
-                    for (int c = 0; c < CPL; c++) {
-                        if (!vnode[c]) continue;
-                        double z;
-                        if (NZ_LDS) {
-                            z = W.template ld<V_NZ>(c * WAVE + lane);
-                        } else {
-                            z = io.base_noise[member * D + lane * CPL + c];
-                            for (int k = 0; k < failed; k++) z *= 0.8;
-                        }
-                        io.base_noise[member * D + lane * CPL + c] = z;
-                    }
-                    if (!NZ_LDS) __threadfence_block();   // the next row's reads of the neighbour lane's nodes see it
+                    for (int c = 0; c < CPL; c++)
+                        if (vnode[c]) io.base_noise[member * D + lane * CPL + c] = W.template ld<V_NZ>(c * WAVE + lane);
                 }
             }
             if (refresh) fresh_seen++;

@@ -1,4 +1,4 @@
-"""Throughput by depth for a given build: python tools/prof_depth.py <lib.so> D [D ...]  (8 192 members, 2 days)"""
+"""Throughput by depth for a given build: python tools/prof_depth.py <lib.so> D [D ...]  (HC_PROF_MEMBERS or 8 192 members, 2 days)"""
 import os, sys, pathlib, hashlib
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
@@ -18,10 +18,11 @@ for D in map(int, sys.argv[2:]):
     forcing = ForcingDigest(params, frame, cols)
     if OLD:
         forcing.wet_season = forcing.wet_season * 0      # the round-1 library reads the whole byte as its daylight flag
-    sim = EnsembleSimulation(cols, forcing, 8192, seed=1)
+    NM = int(os.environ.get("HC_PROF_MEMBERS", "8192"))
+    sim = EnsembleSimulation(cols, forcing, NM, seed=1)
     sim.advance(48)
     sim.kernel_ms = 0.0
     sim.advance(96)
-    print(f"{_lib.LIB_PATH.name} D={D}: {8192 * 2 / (sim.kernel_ms * 1e-3):.0f} column-days/s, "
+    print(f"{_lib.LIB_PATH.name} D={D}: {NM * 2 / (sim.kernel_ms * 1e-3):.0f} column-days/s ({NM} members), "
           f"sha {hashlib.sha1(sim.stepper.get_state().tobytes()).hexdigest()[:10]}", flush=True)
     sim.close()
