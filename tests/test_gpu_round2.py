@@ -269,3 +269,31 @@ def test_failure_accounting_of_the_other_builds_at_depth(gpu, dim_d, build):
         expect = expect * 0.8
     assert np.array_equal(st.get_noise_base(), expect)
     st.close()
+
+
+def test_sweep_scheduler_with_ragged_sizes(gpu, monkeypatch):
+    """Parameter points in one launch when nothing divides evenly: 3 points x 50 members, chunks of 7 (the last chunk of a
+    point holds one member), more workgroups than chunks -- against each point in a handle of its own."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import SweepSimulation, merge_parameters
+    from hydromodel_amd.synthetic import default_parameters
+    params = default_parameters()
+    pts = [{"Soil_Properties": {"n": 2.0}}, {"Soil_Properties": {"n": 1.6, "a0": 0.02}},
+           {"Soil_Properties": {"psi_sat": -0.3}, "Hydraulic_Conductivity": {"Lambda_Exponent": 1.2}}]
+    cols_all = [ColumnTables(merge_parameters(params, p), WELLS[1]) for p in pts]
+    forcing = ForcingDigest(params, forcing_frame(1), cols_all[0])
+    ic = golden("g1_tables_1.npz")["initial_cond"]
+    psi0 = np.stack([ic, ic + 3.0, ic - 5.0])
+    monkeypatch.setenv("HYDROCOL_CHUNK_MEMBERS", "7")
+    big = SweepSimulation(cols_all, forcing, 50, seed=9, psi0=psi0)
+    big.advance(30, want_wtd=True)
+    monkeypatch.delenv("HYDROCOL_CHUNK_MEMBERS")
+    m_big, y_big = big.moments(), big.stepper.get_state()
+    big.close()
+    for j in range(3):
+        one = SweepSimulation([cols_all[j]], forcing, 50, seed=9, first_point=j, psi0=psi0[j])
+        one.advance(30)
+        assert np.array_equal(one.stepper.get_state(), y_big[50 * j:50 * (j + 1)]), j
+        assert np.array_equal(one.moments()[0], m_big[j]), j
+        one.close()
+    assert np.array_equal(m_big[:, 0, 1:31], np.full((3, 30), 50))
