@@ -83,32 +83,73 @@ def _gamma_pdf(x, shape, scale):
 
 
 # --------------------------------------------------------------------------- parameter holders
+class _Checked:
+    """Data descriptor: an attribute whose every assignment goes through ``rule(owner, value)``, which returns the
+    value to store or raises ValueError -- the reference's holders do the same with one property setter per field."""
+
+    def __init__(self, rule):
+        self.rule = rule
+
+    def __set_name__(self, owner, name):
+        self.slot = "_" + name
+        self.name = name
+
+    def __get__(self, obj, owner=None):
+        return self if obj is None else getattr(obj, self.slot)
+
+    def __set__(self, obj, value):
+        setattr(obj, self.slot, self.rule(obj, self.name, value))
+
+
+def _require(cond_text, cond):
+    def rule(obj, name, value):
+        if not cond(value):
+            raise ValueError(f" {type(obj).__name__}: '{name}' = {value} {cond_text}.")
+        return value
+    return rule
+
+
 class SoilProperties:
-    """code/src/soil_properties.py:13-48 (range checks and clamps)."""
+    """code/src/soil_properties.py:13-160: n > 1, alpha > 0 (ValueError otherwise, at construction and on assignment);
+    psi_sat is clamped to <= 0, epsilon to >= 1e-8."""
+
+    n = _Checked(_require("should be > 1", lambda v: v > 1.0))
+    alpha = _Checked(_require("should be strictly positive", lambda v: v > 0.0))
+    psi_sat = _Checked(lambda obj, name, v: float(np.minimum(v, 0.0)))
+    epsilon = _Checked(lambda obj, name, v: float(np.maximum(v, 1.0e-8)))
 
     def __init__(self, n=2.0, alpha=0.009, psi_sat=-100.0, epsilon=1.0e-7):
-        if not n > 1.0:
-            raise ValueError(" SoilProperties: Soil property 'n' should be > 1.")
-        if not alpha > 0.0:
-            raise ValueError(" SoilProperties: Soil property 'alpha' should be strictly positive.")
-        self.n = n
-        self.alpha = alpha
-        self.psi_sat = float(np.minimum(psi_sat, 0.0))
-        self.epsilon = float(np.maximum(epsilon, 1.0e-8))
+        self.n, self.alpha, self.psi_sat, self.epsilon = n, alpha, psi_sat, epsilon
 
     @property
     def m(self):
         return 1.0 - (1.0 / self.n)
 
 
+def _water_content_rule(obj, name, value):
+    """Clip to [0, 1], then 0 <= res < min < max <= 1 must still hold (water_content.py:55-76, 88-190); a value that breaks
+    the ordering is refused and the old one kept."""
+    value = float(np.maximum(np.minimum(1.0, value), 0.0))
+    trial = {k: getattr(obj, "_" + k, None) for k in ("res", "min", "max")}
+    trial[name] = value
+    if None not in trial.values() and not (0.0 <= trial["res"] < trial["min"] < trial["max"] <= 1.0):
+        raise ValueError(f" {type(obj).__name__}: The volumetric water content input values are incorrect.")
+    return value
+
+
 class WaterContent:
-    """code/src/water_content.py:13-76."""
+    """code/src/water_content.py:13-240.  wlt / flc are pressure heads in cm and may be negative."""
+
+    min = _Checked(_water_content_rule)
+    max = _Checked(_water_content_rule)
+    res = _Checked(_water_content_rule)
 
     def __init__(self, minimum=0.08, maximum=0.30, residual=0.05, wilting=-1500.0, field_cap=340.0):
         clip = lambda v: float(np.maximum(np.minimum(1.0, v), 0.0))  # noqa: E731
-        self.min, self.max, self.res = clip(minimum), clip(maximum), clip(residual)
-        if not (0.0 <= self.res < self.min < self.max <= 1.0):
+        lo, hi, res = clip(minimum), clip(maximum), clip(residual)
+        if not (0.0 <= res < lo < hi <= 1.0):
             raise ValueError(" WaterContent: The volumetric water content input values are incorrect.")
+        self._res, self._min, self._max = res, lo, hi
         self.wlt = wilting
         self.flc = field_cap
 
@@ -118,18 +159,19 @@ class WaterContent:
 
 
 class HydraulicConductivity:
-    """code/src/hydraulic_conductivity.py:12-60."""
+    """code/src/hydraulic_conductivity.py:12-240: the three saturated conductivities must be > 0, sigma_noise and
+    lambda_exponent >= 0 (ValueError otherwise, at construction and on assignment)."""
+
+    sat_soil = _Checked(_require("should be strictly positive", lambda v: v > 0.0))
+    sat_saprolite = _Checked(_require("should be strictly positive", lambda v: v > 0.0))
+    sat_fresh_bedrock = _Checked(_require("should be strictly positive", lambda v: v > 0.0))
+    sigma_noise = _Checked(_require("should be non-negative", lambda v: v >= 0.0))
+    lambda_exponent = _Checked(_require("should be non-negative", lambda v: v >= 0.0))
 
     def __init__(self, sat_soil=8.5, sat_saprolite=3.2, sat_fresh_bedrock=0.1,
                  sigma_noise=2.0, lambda_exponent=1.0):
-        for name, v in (("Soil", sat_soil), ("Saprolite", sat_saprolite),
-                        ("Fresh Bedrock", sat_fresh_bedrock)):
-            if not v > 0.0:
-                raise ValueError(f" HydraulicConductivity: The saturated value of the {name} layer: "
-                                 f" {v} should be strictly positive.")
-        self.sat_soil = sat_soil
-        self.sat_saprolite = sat_saprolite
-        self.sat_fresh_bedrock = sat_fresh_bedrock
+        self.sat_soil, self.sat_saprolite, self.sat_fresh_bedrock = sat_soil, sat_saprolite, sat_fresh_bedrock
+        # the constructor clamps these two at zero (hydraulic_conductivity.py:56-57); only assignment raises
         self.sigma_noise = float(np.maximum(sigma_noise, 0.0))
         self.lambda_exponent = float(np.maximum(lambda_exponent, 0.0))
 

@@ -13,6 +13,7 @@ Usage:
     python tests/golden/make_golden.py traj 101   # G5 trajectory, well 1 (D=101), ~8 min
     python tests/golden/make_golden.py traj 200   # G5 trajectory, synthetic D=200, ~8 min
     python tests/golden/make_golden.py points     # G1-G4 at three non-default (a0, psi_sat, lambda, sigma) points, ~1 min
+    python tests/golden/make_golden.py profiles   # G1 tables for the Constant / Linear / Exponential porosity and the other root pdfs
     python tests/golden/make_golden.py points_short  # first 240 rows of year-long runs at two of those points, ~1 min
     python tests/golden/make_golden.py short      # first days of vanGenuchten / HLIFT / ET+LF-off runs, ~1 min
 
@@ -483,6 +484,15 @@ def main(argv):
                 _save(f"g1p_tables_{tag}.npz", g1_tables(sim))
                 _save(f"g2p_pointwise_{tag}.npz", g2_pointwise(sim))
                 _save(f"g34p_states_{tag}.npz", g34_states(sim))
+        elif mode == "profiles":
+            # G1 for the other porosity / root-density profile types (static tables only; well D=200)
+            for por, root in (("Constant", "Uniform"), ("Linear", "Gamma_pdf"), ("Exponential", "Mixture")):
+                ov = {"Hydrological_Model": {"Porosity_Profile": por}, "Trees": {"Root_Pdf_Profile": root}}
+                sim, _, _ = _setup(200, tmp, overrides=ov)
+                g = g1_tables(sim)
+                keep = ("por_node", "fc_node", "wlt_node", "por_mid", "fc_mid", "wlt_mid", "root_mid", "max_root_depth",
+                        "meank_node", "meank_mid", "initial_cond", "iPsi_50")
+                _save(f"g1q_tables_{por.lower()}_{root.lower()}.npz", {k: g[k] for k in keep})
         elif mode == "points_short":
             # first 240 rows of year-long reference runs at two non-default points (lambda != 1: generic-exponent path)
             for tag in ("a03l13", "s07l08"):

@@ -157,3 +157,26 @@ def test_wet_season_bit_and_skipped_rows():
     p = column_params(cols, forcing.surface_evap)
     assert p.flag_predict == 0 and p.sat_cells == int(cols.sat_cells) == 20
     assert column_params(cols, forcing.surface_evap, {"PREDICT": True}).flag_predict == 1
+
+
+@pytest.mark.parametrize("por,root", [("Constant", "Uniform"), ("Linear", "Gamma_pdf"), ("Exponential", "Mixture")])
+def test_other_profile_types_match_reference_bit_for_bit(por, root):
+    """porosity.py:80-100 and tree_roots.py:57-123: every profile type the ensemble stepper accepts, against tables
+    the reference built itself (g1q_*, `make_golden.py profiles`)."""
+    from helpers import WELLS
+    params = default_parameters()
+    params["Hydrological_Model"]["Porosity_Profile"] = por
+    params["Trees"]["Root_Pdf_Profile"] = root
+    cols = dg.ColumnTables(params, WELLS[200])
+    g = golden(f"g1q_tables_{por.lower()}_{root.lower()}.npz")
+    for mine, ref in ((cols.por_raw, "por_node"), (cols.fc_raw, "fc_node"), (cols.wlt_raw, "wlt_node"),
+                      (cols.por_mid, "por_mid"), (cols.fc_mid, "fc_mid"), (cols.wlt_mid, "wlt_mid"),
+                      (cols.meank_node, "meank_node"), (cols.meank_mid, "meank_mid")):
+        assert np.array_equal(mine, g[ref]), ref
+    nr = cols.n_root_first + cols.n_root_int
+    if root == "Uniform":
+        assert np.array_equal(cols.root_mid[:nr], g["root_mid"])
+    else:
+        # gamma pdf: this repo evaluates exp((a-1) log x - x - lgamma(a)) where scipy.stats goes through xlogy / gammaln
+        assert np.allclose(cols.root_mid[:nr], g["root_mid"], rtol=1e-13, atol=0)
+    assert cols.max_root_depth == float(g["max_root_depth"]) and cols.ipsi50 == float(g["iPsi_50"])
