@@ -297,3 +297,41 @@ def test_sweep_scheduler_with_ragged_sizes(gpu, monkeypatch):
         assert np.array_equal(one.moments()[0], m_big[j]), j
         one.close()
     assert np.array_equal(m_big[:, 0, 1:31], np.full((3, 30), 50))
+
+
+@pytest.mark.parametrize("por,root", [("Constant", "Uniform"), ("Linear", "Gamma_pdf"), ("Exponential", "Mixture")])
+def test_other_profile_types_run_like_the_oracle(gpu, por, root):
+    """the other porosity profiles and root densities only change the static tables; one day from the
+    reference's own spin-up state of that configuration (g1q_*), RHS and 48 chained rows against the oracle."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.synthetic import default_parameters
+    from oracle.oracle import Oracle
+    params = default_parameters()
+    params["Hydrological_Model"]["Porosity_Profile"] = por
+    params["Trees"]["Root_Pdf_Profile"] = root
+    cols = ColumnTables(params, WELLS[200])
+    forcing = ForcingDigest(params, forcing_frame(1), cols)
+    ic = golden(f"g1q_tables_{por.lower()}_{root.lower()}.npz")["initial_cond"]
+    N, D, rows = 3, cols.dim_d, 48
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal((N, D))
+    o = Oracle(cols, forcing.surface_evap)
+    st = gpu.EnsembleStepper(cols, forcing, N)
+    st.set_state(ic)
+    st.set_noise_host(base)
+    for row in (2, 24):
+        dydt = st.rhs(row)
+        ref = o.rhs(Oracle.row(forcing.precip[row], forcing.atm[row], forcing.daylight[row], forcing.wtd_obs[row]),
+                    ic, base[0])
+        assert rel_err(dydt[0], ref) < 1e-7
+    nf = st.n_refresh(1, rows)
+    fresh = rng.standard_normal((nf, N, D))
+    out = st.step_rows(1, rows, fresh_noise=fresh, want_wtd=True, want_psi=True)
+    st.close()
+    for k in range(N):
+        r = o.run(forcing, ic, base[k], fresh[:, k, :], 1, 1 + rows, want_psi=True)
+        want = r["psi_rows"][1:1 + rows]
+        e = np.max(np.abs(out["psi"][:, k, :] - want) / (1 + np.abs(want)), axis=1)
+        # chained rows: 1e-9 on the first, transients up to 5e-3 (measured 1.3e-3), back below 1e-3 at the end
+        assert e[0] < 1e-9 and e.max() < 5e-3 and e[-1] < 1e-3, (por, k, e[0], e.max(), e[-1])
+        assert (out["wtd"][:, k] == r["wtd_est"][1:1 + rows]).mean() >= 0.95
