@@ -977,6 +977,17 @@ int hc_get_moments(hc_handle *h, int64_t *moments)
     return HC_OK;
 }
 
+int hc_export_moments(hc_handle *h, void *device_dst)
+{
+    if (!h || !device_dst) return fail(HC_ERR_ARG, "hc_export_moments: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int rc = ensure_moments(h)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(device_dst, h->moments.p, (size_t)h->n_points * 3 * h->n_rows * 8, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    return HC_OK;
+}
+
 int hc_set_moments(hc_handle *h, const int64_t *moments)
 {
     if (!h || !moments) return fail(HC_ERR_ARG, "hc_set_moments: bad argument");

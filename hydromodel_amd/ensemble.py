@@ -213,6 +213,23 @@ def allreduce_moments(moments, device, force=False):
     return t.cpu().numpy()
 
 
+def allreduce_stepper_moments(stepper, device, force=False):
+    """The run's one collective, on device memory end to end: the stepper's moment table ([3][T] or [P][3][T]) is copied
+    device-to-device into a torch tensor (``hc_export_moments``), summed over the ranks with ``all_reduce`` (RCCL when
+    the backend is nccl) and only then brought to the host.  Other backends (gloo rehearsals) and single-rank runs go
+    through :func:`allreduce_moments` on the host copy."""
+    import torch
+    import torch.distributed as dist
+    active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
+    if not active or dist.get_backend() != "nccl":
+        return allreduce_moments(stepper.moments(), device, force=force)
+    shape = (3, stepper.T) if stepper.P == 1 else (stepper.P, 3, stepper.T)
+    t = torch.empty(shape, dtype=torch.int64, device=device)
+    stepper.export_moments(t.data_ptr())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
 def merge_parameters(params, override):
     """``params`` with the sections of ``override`` ({"Soil_Properties": {...}, ...}) merged in (a deep copy)."""
     import copy

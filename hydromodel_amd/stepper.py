@@ -179,6 +179,10 @@ class EnsembleStepper:
         L.check(self.lib.hc_get_moments(self.h, L.lptr(m)))
         return m[0] if self.P == 1 else m
 
+    def export_moments(self, device_ptr):
+        """Copy the moment table device-to-device to `device_ptr` (P * 3 * T int64 on this handle's device)."""
+        L.check(self.lib.hc_export_moments(self.h, C.c_void_p(int(device_ptr))))
+
     def set_moments(self, m):
         m = np.ascontiguousarray(m, dtype=np.int64)
         if m.size != self.P * 3 * self.T:

@@ -191,6 +191,10 @@ int hc_set_iteration_budget(hc_handle *h, int32_t phase_steps);
 /* moments: [n_points][3][n_forcing_rows] int64 = count, sum(idx), sum(idx^2) of wtd_est over the members of each
  * parameter point ([3][n_forcing_rows] for the usual single point); not available for spin-up solves */
 int hc_get_moments(hc_handle *h, int64_t *moments);
+/* The same table copied device-to-device into caller-owned memory on the handle's device (n_points * 3 * n_rows
+ * int64): the buffer a collective (RCCL all-reduce over the ranks' tables) works on, without a host round trip.
+ * Complete when the call returns. */
+int hc_export_moments(hc_handle *h, void *device_dst);
 int hc_set_moments(hc_handle *h, const int64_t *moments);
 int hc_reset_moments(hc_handle *h);
 

@@ -157,6 +157,17 @@ def test_rccl_allreduce_of_the_moment_table_on_one_gpu(gpu):
         assert red.dtype == np.int64 and np.array_equal(red, m)
         pts = np.stack([m, 2 * m])                                   # [P][3][T] tables of a sweep go the same way
         assert np.array_equal(allreduce_moments(pts, dev, force=True), pts)
+        # the path bench.py takes: table exported device-to-device, reduced on the device, copied back once
+        from hydromodel_amd.ensemble import allreduce_stepper_moments
+        st = gpu.EnsembleStepper(cols, forcing, 64)
+        st.set_state(golden("g1_tables_200.npz")["initial_cond"])
+        st.set_noise_philox(3, 0)
+        st.step_rows(1, 48)
+        assert np.array_equal(allreduce_stepper_moments(st, dev, force=True), m)
+        t = torch.zeros((3, st.T), dtype=torch.int64, device=dev)
+        st.export_moments(t.data_ptr())
+        assert np.array_equal(t.cpu().numpy(), m)
+        st.close()
     finally:
         if created:
             dist.destroy_process_group()
