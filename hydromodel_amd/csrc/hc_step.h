@@ -40,7 +40,12 @@ constexpr int WAVE_SCRATCH = 192;
 #else
 constexpr int WAVE_SCRATCH = 160;
 #endif
-constexpr int WAVES_PER_BLOCK = 4;          // one wave per SIMD for every column depth
+#ifndef HC_WAVES_PER_BLOCK
+#define HC_WAVES_PER_BLOCK 4
+#endif
+// One wave per SIMD at every column depth.  (-DHC_WAVES_PER_BLOCK=8 is the two-waves-per-SIMD experiment of DESIGN.md §5:
+// the compiler is held to 256 registers per wave and half of the per-wave vectors move to the global region.)
+constexpr int WAVES_PER_BLOCK = HC_WAVES_PER_BLOCK;
 constexpr int LDS_BYTES = 160 * 1024;
 // Where they live.  Up to CPL = 5 (D <= 320) all twelve fit in LDS next to the shared tables with four waves per
 // workgroup.  Deeper columns keep four waves per CU -- every SIMD busy -- by moving the vectors that are touched least
@@ -496,7 +501,7 @@ enum Phase {
 };
 
 template <int CPL, bool SPECIAL, int WPB, bool PREDICT>
-__global__ __launch_bounds__(WPB * WAVE, 1) void step_kernel(const StepArgs A)
+__global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArgs A)
 {
     constexpr int SLOTS = WAVE * CPL;
     extern __shared__ double lds[];
