@@ -497,6 +497,7 @@ def main(argv):
             # first 240 rows of year-long reference runs at two non-default points (lambda != 1: generic-exponent path)
             for tag in ("a03l13", "s07l08"):
                 _save(f"g5sp_{tag}_200.npz", g5_short(200, tmp, 240, overrides=POINTS[tag]))
+            _save("g5sp_vg_a003_200.npz", g5_short(200, tmp, 240, model="vanGenuchten", overrides=POINTS["a003"]))
         elif mode == "traj":
             well = int(argv[2])
             _save(f"g5_traj_{well}.npz", g5_trajectory(well, tmp))

@@ -133,12 +133,14 @@ def test_two_days_at_the_point_match_the_oracle(gpu, tag):
     assert equal >= 0.98 * total, (equal, total)
 
 
-@pytest.mark.parametrize("tag", ["a03l13", "s07l08"])
-def test_first_days_of_the_reference_run_at_the_point_replay_on_the_gpu(gpu, tag):
+@pytest.mark.parametrize("tag,model,fname", [("a03l13", "vrettas_fung", "g5sp_a03l13_200.npz"),
+                                             ("s07l08", "vrettas_fung", "g5sp_s07l08_200.npz"),
+                                             ("a003", "vanGenuchten", "g5sp_vg_a003_200.npz")])
+def test_first_days_of_the_reference_run_at_the_point_replay_on_the_gpu(gpu, tag, model, fname):
     """240 rows recorded inside the reference's own year-long run at the point (lambda != 1: the generic-exponent kernel),
     each replayed from the reference's input state and noise vector."""
-    _, cols, forcing = digest_point(tag)
-    g = golden(f"g5sp_{tag}_200.npz")
+    _, cols, forcing = digest_point(tag, model)
+    g = golden(fname)
     st = gpu.EnsembleStepper(cols, forcing, 1)
     errs, same = [], 0
     for k, i in enumerate(g["rows"]):

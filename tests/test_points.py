@@ -111,12 +111,14 @@ def test_single_row_solve_at_the_point_matches_the_reference(tag):
     assert total >= 12 and same == total, (same, total)
 
 
-@pytest.mark.parametrize("tag", ["a03l13", "s07l08"])
-def test_first_days_of_the_reference_run_at_the_point_replay(tag):
+@pytest.mark.parametrize("tag,model,fname", [("a03l13", "vrettas_fung", "g5sp_a03l13_200.npz"),
+                                             ("s07l08", "vrettas_fung", "g5sp_s07l08_200.npz"),
+                                             ("a003", "vanGenuchten", "g5sp_vg_a003_200.npz")])
+def test_first_days_of_the_reference_run_at_the_point_replay(tag, model, fname):
     """First 240 rows of the reference's own year-long run at the point (lambda != 1), replayed row by row."""
-    _, cols, forcing = digest_point(tag)
+    _, cols, forcing = digest_point(tag, model)
     o = Oracle(cols, forcing.surface_evap)
-    g = golden(f"g5sp_{tag}_200.npz")
+    g = golden(fname)
     assert g["rows"].tolist() == list(range(1, 241))
     errs, same = [], 0
     for k, i in enumerate(g["rows"]):
