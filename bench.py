@@ -1,30 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- ensemble column-days/s of the MI355X Richards-column stepper.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process starts the N ranks itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same thing, pre-launched)
 
-A "step" is ONE SIMULATED DAY (48 half-hour forcing rows) for every member of the rank's
-shard.  Workload (BASELINE.json configs[2], the one the metric is quoted on): 262 144 members
-per GPU, D = 300 depth nodes, 10-year synthetic forcing digest (175 200 rows), fp64, Philox
-noise generated in-kernel, shared initial condition from the member-0 spin-up; the timed region
-covers the K days after the W warm-up days (a prefix of the 10-year run -- SURVEY.md §8d; default
-K = 30: days 2..31.  The first days after the spin-up are the costliest, a whole year of the 1-year
-forcing sustains ~206 k column-days/s: DESIGN.md §5 "Soak").
-Members shard across ranks with no communication while stepping ("weak" scaling: per-GPU
-members fixed); the single collective -- the int64 all-reduce of the per-row water-table
-moments over RCCL -- runs after the timed region and is reported separately.
+A "step" is ONE SIMULATED DAY (48 half-hour forcing rows) for every member of the rank's shard.
 
-Prints ONE JSON line (rank 0).  roofline.achieved uses the algorithmic bytes of SURVEY.md §8d,
-(16*D + 16) B per column-step, over the step kernel's mean launch duration measured with HIP
-events on the library's stream.  Two more legs run AFTER the timed region on rank 0 of a one-GPU run:
-`sustained` -- 16 384 members through the first 365 days of the same forcing digest (what the stepper holds
-over a whole simulated year, with the failed-attempt / iteration-guard counters) -- and `cpu_baseline` -- the C oracle
-(oracle/, a port of the same algorithm) on every host core this process may use, for >= 30 s.
+--workload ensemble (default; BASELINE.json configs[2], the one the metric is quoted on; x N GPUs = configs[3]):
+262 144 members per GPU, D = 300 depth nodes, 10-year synthetic forcing digest (175 200 rows), fp64, Philox noise
+generated in-kernel, shared initial condition from the member-0 spin-up; the timed region covers the K days after
+the W warm-up days (a prefix of the 10-year run -- SURVEY.md §8d; default K = 30: days 2..31).  Members shard across
+ranks with no communication while stepping ("weak" scaling: per-GPU members fixed); the single collective -- the int64
+all-reduce of the per-row water-table moments over RCCL -- runs after the timed region and is reported separately.
+
+--workload sweep (BASELINE.json configs[4]): a P-point (n, a0, psi_sat) grid (default 8 x 8 x 8 = 512) x
+4 096 members each, D = 300, 1-year forcing, every point from its own spin-up; whole points are dealt to ranks
+round-robin ("strong" scaling: the grid is fixed), all of a rank's points advance in ONE launch per day.
+
+Prints ONE JSON line (rank 0).  roofline.achieved uses the algorithmic bytes of SURVEY.md §8d, (16*D + 16) B per
+column-step, over the step kernel's mean launch duration measured with HIP events on the library's stream.  More legs
+run AFTER the timed region on rank 0 of a one-GPU ensemble run: `sustained` -- 16 384 members through the first 365 days
+of the same (10-year, quiet) digest; `sustained_heavy` -- 16 384 members through the whole 1-YEAR forcing, ten times the
+evapo-transpiration per row, the regime with failed BDF attempts; `cpu_baseline` -- the C oracle (oracle/, a port of the
+same algorithm) on every host core this process may use, for >= 30 s.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -37,38 +41,66 @@ sys.path.insert(0, str(REPO))
 
 ROWS_PER_DAY = 48
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-# HBM bytes per member per 48-row launch at D=300, from rocprofv3 PMC passes on this launch shape
-# (profiles/r02_pmc_fetch_size.csv, r02_pmc_write_size.csv; `tools/prof_traffic.py 65536`, dispatch 12; N = 65 536):
-# 2 x FETCH_SIZE (gfx950 counts half of the fetched bytes -- confirmed by dispatch 9 of the same run, a calibration
-# launch that only loads and stores psi: 153 600 KiB each way, FETCH_SIZE 78 024.5, WRITE_SIZE 154 624)
-# + WRITE_SIZE = (2 x 78 574.5 + 178 688) KiB / 65 536 members = 5.1 KiB.
-PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 = (2 * 78574.5 + 178688.0) * 1024.0 / 65536.0
-# fp64 work per column-step at D=300 from rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 summed over the 31 ensemble
-# launches of this very bench (profiles/r02_pmc_sq_f64_bench.csv; wave instructions per column-step: 2 019.5 / 3 674.7 /
-# 7 846.5 / 685.3 -- unchanged from round 1; x64 lanes, FMA = 2 flop) -- the secondary, honest roofline.
-PMC_F64_FLOP_PER_COLUMN_STEP_D300 = (2019.5 + 3674.7 + 685.3 + 2 * 7846.5) * 64.0
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
+# Per-kernel constants from rocprofv3 PMC passes (profiles/README.md says which files), keyed by (depth nodes, cell model):
+#   hbm_bytes_per_member_launch: 2 x FETCH_SIZE (gfx950 counts half of the fetched bytes -- confirmed by a calibration
+#     dispatch that only loads and stores psi) + WRITE_SIZE, in bytes per member of a 48-row launch;
+#   f64_flop_per_column_step: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 wave instructions x 64 lanes, FMA = 2 flop.
+PMC = {
+    (300, "special"): {"hbm_bytes_per_member_launch": (2 * 78574.5 + 178688.0) * 1024.0 / 65536.0,
+                       "f64_flop_per_column_step": (2019.5 + 3674.7 + 685.3 + 2 * 7846.5) * 64.0,
+                       "source": "profiles/r02_pmc_fetch_size.csv, r02_pmc_write_size.csv, r02_pmc_sq_f64_bench.csv"},
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30,
-                    help="timed simulated days (one 48-row launch each); the default month takes ~30 s on one MI355X")
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed simulated days (one 48-row launch each); default 30 (ensemble: ~30 s) or 2 (sweep: ~60 s)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--members", type=int, default=262144, help="members per GPU")
+    ap.add_argument("--workload", choices=("ensemble", "sweep"), default="ensemble")
+    ap.add_argument("--members", type=int, default=None,
+                    help="ensemble: members per GPU (default 262 144); sweep: members per parameter point (default 4 096)")
     ap.add_argument("--depth", type=int, default=300)
-    ap.add_argument("--years", type=int, default=10)
+    ap.add_argument("--years", type=int, default=None, help="forcing length (default: 10 for the ensemble, 1 for the sweep)")
+    ap.add_argument("--points", type=int, default=512, help="sweep: grid points, a cube (n x a0 x psi_sat)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="wall time of the CPU leg (BASELINE.md §3: >= 30 s)")
     ap.add_argument("--no-sustained", action="store_true")
     ap.add_argument("--sustained-members", type=int, default=16384)
     ap.add_argument("--sustained-days", type=int, default=365)
+    ap.add_argument("--no-heavy", action="store_true")
+    ap.add_argument("--heavy-members", type=int, default=16384)
+    ap.add_argument("--heavy-days", type=int, default=364)
     ap.add_argument("--ic-file", default="", help="npz cache of the spun-up initial condition (written if missing)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
-    return ap.parse_args()
+    ap.add_argument("--probe-ranks", action="store_true",
+                    help="only start the ranks, all-reduce a one and print what the process group saw (no GPU work)")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 30 if args.workload == "ensemble" else 2
+    if args.members is None:
+        args.members = 262144 if args.workload == "ensemble" else 4096
+    if args.years is None:
+        args.years = 10 if args.workload == "ensemble" else 1
+    return args
+
+
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes (one per
+    GPU, torch.distributed.run on 127.0.0.1) and hand their output through.  Runs before this process has imported
+    torch or touched the GPU; nothing is re-executed in place, nothing is retried.  Returns the launcher's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def host_cores():
@@ -130,12 +162,13 @@ def cpu_baseline(cols, forcing, psi0, threads, seconds, first_row=1 + ROWS_PER_D
             "per_core": days / wall / threads, "host_cores_total": total, "host_cores_usable": usable,
             "sample": f"{done} members x {rows} rows (days {(first_row - 1) // ROWS_PER_DAY + 1}.."
                       f"{(first_row - 1) // ROWS_PER_DAY + days_per_member}, D={D}) of the same forcing, C oracle, "
-                      f"{threads} threads (every core this process may use: affinity mask and cgroup quota), {wall:.1f} s wall"}
+                      f"{threads} threads (the {usable}-core share of the {total}-core host this process may use: "
+                      f"affinity mask and cgroup quota), {wall:.1f} s wall"}
 
 
-def sustained_leg(cols, forcing, psi0, members, days, seed, device):
-    """What the stepper sustains over a whole simulated year: `members` members through the first `days` days of the
-    same digest, in 30-day requests that the library splits into launches of its own choosing, with the failed-attempt
+def sustained_leg(cols, forcing, psi0, members, days, seed, device, label):
+    """What the stepper sustains over a whole simulated year: `members` members through the first `days` days of
+    `forcing`, in 30-day requests that the library splits into launches of its own choosing, with the failed-attempt
     and iteration-guard counters of the run."""
     from hydromodel_amd.ensemble import EnsembleSimulation
     days = min(days, (forcing.dim_t - 1) // ROWS_PER_DAY)
@@ -156,34 +189,142 @@ def sustained_leg(cols, forcing, psi0, members, days, seed, device):
            "failed_attempts_per_member_year": cnt["failed_attempts"] / members * 365.0 / days,
            "wtd_mean_cm_last_row": float(mean_cm[last]), "wtd_std_cm_last_row": float(std_cm[last]),
            "wtd_std_cm_max": float(np.nanmax(std_cm[1:last + 1])),
-           "workload": f"{members} members x D={cols.dim_d}, days 1..{days} of the same {forcing.dim_t}-row digest"}
+           "workload": f"{members} members x D={cols.dim_d}, days 1..{days} of {label} ({forcing.dim_t} rows)"}
     sim.close()
     return out
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def probe_ranks(args, rank, world):
+    """--probe-ranks: what did the launcher start?  Every rank joins the process group and adds a one."""
     import torch
     import torch.distributed as dist
-    n_dev = max(torch.cuda.device_count(), 1)
-    dev_index = local_rank % n_dev                 # one rank per GPU; a gloo rehearsal may share a card
     if world > 1:
-        torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
+            dev_index = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(dev_index)
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            t = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend)
-    dev = torch.device("cuda", dev_index)
-    local_rank = dev_index
+            t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen, ranks, backend = int(t.item()), dist.get_world_size(), dist.get_backend()
+        dist.destroy_process_group()
+    else:
+        seen, ranks, backend = 1, 1, None
+    if rank == 0:
+        print(json.dumps({"probe": True, "n_gpus": world, "ranks": ranks, "ranks_counted": seen, "backend": backend}))
 
+
+def sweep_grid(n_points):
+    """n in linspace(1.5, 3.0, k), a0 in geomspace(0.003, 0.03, k), psi_sat in -geomspace(1e-3, 1.0, k)."""
+    k = round(n_points ** (1.0 / 3.0))
+    if k ** 3 != n_points:
+        raise SystemExit(f"--points {n_points} is not a cube (n x a0 x psi_sat grid)")
+    return [(float(n), float(a0), float(ps)) for n in np.linspace(1.5, 3.0, k) for a0 in np.geomspace(0.003, 0.03, k)
+            for ps in -np.geomspace(1e-3, 1.0, k)]
+
+
+def run_sweep(args, rank, world, dev, dist):
+    import torch
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import SweepSimulation, check_sweep_points, deal_points
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    grid = sweep_grid(args.points)
+    pts = [{"Soil_Properties": {"n": n, "a0": a0, "psi_sat": ps}} for n, a0, ps in grid]
+    merged = check_sweep_points(params, pts)
+    mine = deal_points(len(pts), rank, world)
+    well = synthetic_well(args.depth)
+    cols_list = [ColumnTables(merged[k], well) for k in mine]
+    forcing = ForcingDigest(params, synthetic_forcing_frame(args.years), cols_list[0])
+    D, M, P = cols_list[0].dim_d, args.members, len(pts)
+    need_rows = 1 + (args.warmup + args.steps) * ROWS_PER_DAY
+    if need_rows > forcing.dim_t:
+        raise SystemExit(f"forcing has {forcing.dim_t} rows, need {need_rows}")
+    t_spin = time.perf_counter()
+    sim = SweepSimulation(cols_list, forcing, M, seed=args.seed, device=dev.index, point_ids=mine)
+    spin_s = time.perf_counter() - t_spin
+    for _ in range(args.warmup):
+        sim.advance(ROWS_PER_DAY)
+    sim.kernel_ms, sim.launches = 0.0, 0
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.advance(ROWS_PER_DAY)
+    sync()
+    elapsed = time.perf_counter() - t0
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
+
+    n_local = len(mine) * M
+    cnt = sim.stepper.counters()
+    cost = sim.stepper.point_costs().astype(np.float64)
+    m = sim.moments()
+    last = sim.next_row - 1
+    top = np.argsort(-cost)[:5]
+    col_days = float(P) * M * args.steps
+    rows_per_launch = ROWS_PER_DAY * args.steps / max(sim.launches, 1)
+    bytes_per_launch = float(n_local) * rows_per_launch * (16 * D + 16)
+    launch_ms = sim.kernel_ms / max(sim.launches, 1)
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    pmc = PMC.get((D, "generic"))
+    out = {
+        "metric": "ensemble column-days/sec", "value": col_days / elapsed, "unit": "column-days/s",
+        "n_gpus": world, "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (("BASELINE.json configs[4]: " if (P == 512 and M == 4096 and D == 300) else "")
+                                + f"{P}-point (n, a0, psi_sat) grid x {M} members each, D={D}, {args.years}-yr half-hourly "
+                                f"synthetic forcing ({forcing.dim_t} rows), vrettas_fung + Stratified, ET+LF on, one "
+                                f"spin-up per point; timed prefix = days {args.warmup + 1}..{args.warmup + args.steps}"),
+                   "points": P, "members_per_point": M, "points_per_gpu": len(mine), "depth_nodes": D,
+                   "rows_per_step": ROWS_PER_DAY, "noise": "philox4x32-10 in-kernel",
+                   "parallelism": f"whole points dealt round-robin x{world}, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": (pmc["hbm_bytes_per_member_launch"] * n_local
+                                 if (pmc and abs(rows_per_launch - 48) < 1e-9) else None),
+                     "traffic_source": pmc["source"] if pmc else None,
+                     "kernel": "hc::step_kernel<5, generic exponents> (rank 0)", "launch_ms": launch_ms,
+                     "launches": sim.launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "note": "fp64-VALU/recurrence bound (SURVEY.md §8d); the costliest points set the pace"},
+        "sweep_rank0": {"spinup_s": spin_s, "spinup_iterations_max": int(np.max(np.abs(sim.spinup_iters))),
+                        "spinup_capped": int((np.asarray(sim.spinup_iters) < 0).sum()),
+                        "failed_attempts": cnt["failed_attempts"], "guard_trips": cnt["guard_trips"],
+                        "rhs_evaluations_per_column_step_min_median_max": [
+                            float(v) / (M * (args.warmup + args.steps) * ROWS_PER_DAY)
+                            for v in (cost.min(), np.median(cost), cost.max())],
+                        "costliest_points": [{"point": int(mine[j]), "n": grid[mine[j]][0], "a0": grid[mine[j]][1],
+                                              "psi_sat": grid[mine[j]][2],
+                                              "rhs_evaluations_per_column_step":
+                                                  float(cost[j]) / (M * (args.warmup + args.steps) * ROWS_PER_DAY)}
+                                             for j in top],
+                        "wtd_mean_cm_last_row_min_max": [float(v) for v in (
+                            cols_list[0].z[0] + 5.0 * (m[:, 1, last] / m[:, 0, last]).min(),
+                            cols_list[0].z[0] + 5.0 * (m[:, 1, last] / m[:, 0, last]).max())]},
+        "sustained": None, "sustained_heavy": None, "cpu_baseline": None,
+    }
+    sim.close()
+    return out
+
+
+def run_ensemble(args, rank, world, dev, dist):
+    import torch
     from hydromodel_amd.digest import ColumnTables, ForcingDigest
     from hydromodel_amd.ensemble import PHILOX_DRAW_SPINUP, EnsembleSimulation, allreduce_stepper_moments, spinup_on_gpu
     from hydromodel_amd.stepper import EnsembleStepper
     from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
-
+    local_rank = dev.index
     params = default_parameters()
     cols = ColumnTables(params, synthetic_well(args.depth))
     forcing = ForcingDigest(params, synthetic_forcing_frame(args.years), cols)
@@ -240,6 +381,7 @@ def main():
     allreduce_s = time.perf_counter() - t1
     mean_cm, std_cm = sim.wtd_mean_std(moments)
     last_row = sim.next_row - 1
+    members_seen = int(moments[0][last_row])                   # count row of the reduced table: every rank's members
 
     col_days = float(N) * world * args.steps
     value = col_days / elapsed
@@ -247,10 +389,12 @@ def main():
     bytes_per_launch = float(N) * rows_per_launch * (16 * D + 16)
     launch_ms = sim.kernel_ms / max(sim.launches, 1)
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    pmc = PMC.get((D, "special"))
 
     out = {
         "metric": "ensemble column-days/sec", "value": value, "unit": "column-days/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("BASELINE.json configs[2] (x8 GPUs = configs[3]): " if (N == 262144 and D == 300) else "")
@@ -261,37 +405,78 @@ def main():
                    "noise": "philox4x32-10 in-kernel", "parallelism": f"members sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": (PMC_HBM_BYTES_PER_MEMBER_LAUNCH_D300 * N
-                                 if (D == 300 and abs(rows_per_launch - 48) < 1e-9) else None),
-                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same launch shape "
-                                       "(profiles/r02_pmc_*_size.csv), scaled by members; psi stays in LDS for the "
-                                       "48 rows of a launch, so HBM sees ~1/45 of the algorithmic bytes",
+                     "traffic": (pmc["hbm_bytes_per_member_launch"] * N
+                                 if (pmc and abs(rows_per_launch - 48) < 1e-9) else None),
+                     "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same launch shape ({pmc['source']}), "
+                                        "scaled by members; psi stays in LDS for the 48 rows of a launch, so HBM sees "
+                                        "~1/45 of the algorithmic bytes") if pmc else None,
                      "kernel": "hc::step_kernel", "launch_ms": launch_ms, "launches": sim.launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "path is fp64-VALU/recurrence bound (SURVEY.md §8d): ~24 RHS evaluations per "
                              "column-step at ~10^2 flop per byte of state"},
-        "valu_f64": ({"achieved": value * ROWS_PER_DAY * PMC_F64_FLOP_PER_COLUMN_STEP_D300 / 1e12 / world,
+        "valu_f64": ({"achieved": value * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world,
                       "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
-                      "frac": value * ROWS_PER_DAY * PMC_F64_FLOP_PER_COLUMN_STEP_D300 / 1e12 / world
+                      "frac": value * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world
                       / FP64_VALU_PEAK_TFLOPS,
                       "source": "fp64 instruction mix per column-step from rocprofv3 PMC (profiles/README.md)"}
-                     if D == 300 else None),
-        "moments_allreduce_s": allreduce_s,
+                     if pmc else None),
+        "moments_allreduce_s": allreduce_s, "members_in_reduced_moments": members_seen,
         "wtd_mean_cm_last_row": float(mean_cm[last_row]), "wtd_std_cm_last_row": float(std_cm[last_row]),
         "spinup_iterations": spin_iters,
     }
     sim.close()
-    if rank == 0 and world == 1 and not args.no_sustained:
-        out["sustained"] = sustained_leg(cols, forcing, psi0, args.sustained_members, args.sustained_days, args.seed,
-                                         local_rank)
-    elif rank == 0:
-        out["sustained"] = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if members_seen != N * world:
+        raise SystemExit(f"the reduced moment table counts {members_seen} members, expected {N} x {world}")
+    solo = rank == 0 and world == 1
+    out["sustained"] = (sustained_leg(cols, forcing, psi0, args.sustained_members, args.sustained_days, args.seed,
+                                      local_rank, f"the same {args.years}-year digest")
+                        if solo and not args.no_sustained else None)
+    if solo and not args.no_heavy:
+        # the heavy regime: the reference spreads the annual demand over the file length (simulation.py:320-325), so the
+        # 1-year forcing carries ten times the evapo-transpiration per row of the 10-year digest
+        forcing1 = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+        out["sustained_heavy"] = sustained_leg(cols, forcing1, psi0, args.heavy_members, args.heavy_days, args.seed,
+                                               local_rank, "the 1-year forcing")
+    else:
+        out["sustained_heavy"] = None
+    if solo and not args.no_cpu_baseline:
         threads = args.cpu_threads or host_cores()[0]
         out["cpu_baseline"] = cpu_baseline(cols, forcing, psi0, threads, args.cpu_seconds,
                                            first_row=1 + args.warmup * ROWS_PER_DAY)
-    elif rank == 0:
+    else:
         out["cpu_baseline"] = None
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))            # before torch / the GPU are touched by this process
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.probe_ranks:
+        return probe_ranks(args, rank, world)
+    import torch
+    import torch.distributed as dist
+    n_dev = max(torch.cuda.device_count(), 1)
+    if args.backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, {n_dev} visible (use --backend gloo to rehearse)")
+    dev_index = local_rank % n_dev                 # one rank per GPU; a gloo rehearsal may share a card
+    if world > 1:
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    dev = torch.device("cuda", dev_index)
+    out = (run_sweep if args.workload == "sweep" else run_ensemble)(args, rank, world, dev, dist)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

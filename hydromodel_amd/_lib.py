@@ -72,6 +72,11 @@ EXPORTS = {
     "hc_export_moments": ([C.c_void_p, C.c_void_p], C.c_int),
     "hc_set_moments": ([C.c_void_p, _lp], C.c_int),
     "hc_reset_moments": ([C.c_void_p], C.c_int),
+    "hc_allreduce_moments": ([C.POINTER(C.c_void_p), C.c_int], C.c_int),
+    "hc_get_noise_scale": ([C.c_void_p, _dp, C.c_int64, C.c_int64], C.c_int),
+    "hc_set_noise_scale": ([C.c_void_p, _dp, C.c_int64, C.c_int64], C.c_int),
+    "hc_set_point_member_bases": ([C.c_void_p, _lp], C.c_int),
+    "hc_get_point_costs": ([C.c_void_p, C.POINTER(C.c_uint64)], C.c_int),
     "hc_rhs": ([C.c_void_p, C.c_int64, C.c_int32, _dp, _dp], C.c_int),
     "hc_model_nodes": ([C.c_void_p, _dp, _dp], C.c_int),
     "hc_plugin_eval": ([C.c_int, C.POINTER(ColumnParams), C.c_int64, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp],

@@ -119,10 +119,16 @@ def _run_sweep(params, forcing, output_name, ens, n_members, rows, device):
     import numpy as np
     from . import hdf5io
     from .digest import ColumnTables, load_site_well
-    from .ensemble import SweepSimulation, merge_parameters
+    from .ensemble import SweepSimulation, check_sweep_points
     from .stepper import moments_to_mean_std
+    # a sweep runs in-kernel Philox noise from one spin-up per point; anything else is refused, not ignored
+    if str(ens.get("Noise", "philox")).lower() != "philox":
+        raise ValueError(f" Sweep: Ensemble.Noise = {ens.get('Noise')!r} is not supported with Points (philox only).")
+    if str(ens.get("Spinup", "point")).lower() not in ("point", "shared"):
+        raise ValueError(f" Sweep: Ensemble.Spinup = {ens.get('Spinup')!r} is not supported with Points "
+                         f"(one spin-up per parameter point).")
     well = load_site_well(params)
-    points = [ColumnTables(merge_parameters(params, ov), well) for ov in ens["Points"]]
+    points = [ColumnTables(mp, well) for mp in check_sweep_points(params, ens["Points"])]
     sim = SweepSimulation(points, forcing, n_members, seed=int(ens.get("Seed", 0)), device=device)
     done = 0
     while done < rows:

@@ -155,6 +155,11 @@ struct IoArgs {
     unsigned long long *counters;   // [0] FD-Jacobian retry passes, [1] failed attempts, [2] loop-guard trips
     unsigned long long *queue;      // member ticket of the persistent grid, zeroed before every launch
     int *spin_iters;          // [N] spin-up with the stop rule: solves used (negative: cap reached), or null
+    // parameter points (n_points > 1 only):
+    const long long *point_base;     // [n_points] global id of each point's first member: the Philox stream key of member
+                                     // j of point k is point_base[k] + j, whichever handle / rank / order runs the point
+    const int *point_order;          // [n_points] the chunk ticket walks the points in this order (costliest first)
+    unsigned long long *point_cost;  // [n_points] RHS evaluations spent on each point's members by this launch
     double *trace;            // diagnostic builds: [1 + 6 * HC_TRACE_N] phase trace of member 0, or null
 };
 
@@ -582,7 +587,9 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                 const IoArgs io = load_const(A.io);
                 const unsigned long long c = atomicAdd(io.queue, 1ull);
                 if (c < (unsigned long long)A.n_chunks) {
-                    const int pt = (int)(c / (unsigned)A.chunks_per_point);
+                    // longest expected first: the ticket walks the points in the order the host derived from the
+                    // previous launch's per-point cost, so the launch does not end on the costliest point's chunks
+                    const int pt = io.point_order[c / (unsigned)A.chunks_per_point];
                     const long long first = (long long)pt * A.members_per_point +
                                             (long long)(c % (unsigned)A.chunks_per_point) * A.chunk_members;
                     const long long last = (long long)(pt + 1) * A.members_per_point;
@@ -623,6 +630,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     // stale value into the per-row failure count (tools/dev/dbg_failed.py) -- the combination is not used.
     constexpr bool DEEP = CPL >= 6 && CPL <= 8;   // (measured neutral at CPL = 5)
     constexpr bool DEEPY = CPL >= 9;
+    static_assert(!(DEEP && DEEPY), "group ids on demand and the row-start state in the global region are not combined");
     int gs_keep[CPL], gp_keep[CPL], gn_keep[CPL];
     if (!DEEP) {
 #pragma unroll
@@ -654,6 +662,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     }
     int fresh_seen = 0;
     bool nz_is_base = false;     // V_NZ holds this member's base vector exactly as a fresh generation would give it
+    int cost_nfev = 0;           // RHS evaluations of this member in this launch (multi-point mode: per-point cost)
 
     for (int r = 0; r < A.n_rows; r++) {
         RowDev R;
@@ -692,6 +701,9 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                 // Philox draws mirror the reference's order (simulation.py:426,561,601): the spin-up vector has
                 // its own index, 0 is the base vector, refresh row k uses draw k >= 1
                 const unsigned draw = draw_row;
+                // the member's global id keys its Philox stream; with several points each point has a base of its own
+                long long gid = io.member_offset + member;
+                if (multi && !A.host_noise) gid = io.point_base[point] + (member - (long long)point * A.members_per_point);
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
                     const int i = lane * CPL + c;
@@ -701,7 +713,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             z = refresh ? io.fresh[((size_t)fresh_seen * A.n_members + member) * D + i]
                                         : io.base_noise[member * D + i];
                         } else {
-                            z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), draw, (unsigned)i);
+                            z = philox_normal(io.seed, (unsigned long long)gid, draw, (unsigned)i);
                             z = refresh ? z : z * nscale;
                         }
                     }
@@ -795,8 +807,9 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             const IoArgs iog = load_const(A.io);
                             atomicAdd(&iog.counters[2], 1ull);
                             // where it happened (last writer wins): global member id << 24 | forcing row
-                            iog.counters[3] = ((unsigned long long)(iog.member_offset + member) << 24) |
-                                              ((unsigned long long)row & 0xFFFFFFull);
+                            const long long gidg = multi ? iog.point_base[point] + (member - (long long)point * A.members_per_point)
+                                                         : iog.member_offset + member;
+                            iog.counters[3] = ((unsigned long long)gidg << 24) | ((unsigned long long)row & 0xFFFFFFull);
                         }
                         phase = C_FAIL;
                     }
@@ -1269,6 +1282,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     }
                 }
                 st_nfev += nfev;
+                cost_nfev += nfev;
                 st_njev += njev;
                 st_nlu += nlu;
                 st_nsteps = nsteps;
@@ -1355,6 +1369,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         for (int c = 0; c < CPL; c++)
             if (vnode[c]) io.psi[member * D + lane * CPL + c] = W.template ld<V_Y>(c * WAVE + lane);
         if (!A.host_noise && lane == 0) io.nscale[member] = nscale;
+        if (multi && lane == 0) atomicAdd(&io.point_cost[point], (unsigned long long)cost_nfev);
 #ifdef HC_PROFILE
         __builtin_amdgcn_wave_barrier();
         if (lane < 32) atomicAdd(&io.counters[8 + lane], prof_lds[lane]);

@@ -4,8 +4,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
+#include <climits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -100,6 +103,14 @@ struct hc_handle {
     DevBuf<unsigned long long> counters;
     DevBuf<ColumnDev> Pdev;
     DevBuf<IoArgs> iodev;
+    // several parameter points: Philox key of each point's first member, walk order of the chunk ticket, per-point cost
+    DevBuf<long long> point_base;
+    DevBuf<int> point_order;
+    DevBuf<unsigned long long> point_cost;
+    std::vector<long long> base_host;            // set by hc_set_point_member_bases (empty: member_offset + k * members_per_point)
+    std::vector<int> order_host;
+    bool fixed_order = false;                    // HYDROCOL_POINT_ORDER=fixed: keep the walk in point order (A/B timing)
+    std::vector<unsigned long long> cost_total;  // RHS evaluations per point since the points were installed
     IoArgs io_host{};
     std::vector<unsigned char> h_refresh;
     int64_t n_rows = 0, n_members = 0;
@@ -193,7 +204,11 @@ __global__ void model_nodes_kernel(const StepArgs A, const double *node_tabs, in
     if (A.host_noise)
         z = io.base_noise[member * D + i];
     else
-        z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), 0u, (unsigned)i) * io.nscale[member];
+    {
+        const long long gid = A.n_points > 1 ? io.point_base[point] + (member - point * A.members_per_point)
+                                             : io.member_offset + member;
+        z = philox_normal(io.seed, (unsigned long long)gid, 0u, (unsigned)i) * io.nscale[member];
+    }
     double th, K, C, kb, pf;
     if (special)
         model_cell<true>(P, io.psi[k], por, 1.0 / (por - P.theta_res), log(mk), 1.0 / (mk * mk), noisec, noisec * z, th, K, C, kb, pf);
@@ -427,6 +442,25 @@ int fill_args(hc_handle *h, StepArgs &A)
     io.seed = h->seed;
     io.counters = h->counters.p;
     io.queue = h->counters.p + 63;
+    if (NP > 1) {
+        if (h->point_base.ensure((size_t)NP) || h->point_order.ensure((size_t)NP) || h->point_cost.ensure((size_t)NP))
+            return HC_ERR_DEVICE;
+        std::vector<long long> base(h->base_host);
+        if ((int)base.size() != NP) {
+            base.resize((size_t)NP);
+            for (int k = 0; k < NP; k++) base[(size_t)k] = h->member_offset + (long long)k * A.members_per_point;
+        }
+        if ((int)h->order_host.size() != NP) {
+            h->order_host.resize((size_t)NP);
+            for (int k = 0; k < NP; k++) h->order_host[(size_t)k] = k;
+        }
+        if ((int)h->cost_total.size() != NP) h->cost_total.assign((size_t)NP, 0ull);
+        HIP_TRY(hipMemcpy(h->point_base.p, base.data(), (size_t)NP * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->point_order.p, h->order_host.data(), (size_t)NP * 4, hipMemcpyHostToDevice));
+        io.point_base = h->point_base.p;
+        io.point_order = h->point_order.p;
+        io.point_cost = h->point_cost.p;
+    }
 #ifdef HC_PROFILE
     if (getenv("HYDROCOL_DEBUG_TRACE")) {
         if (h->trace.ensure((size_t)1 + 6 * HC_TRACE_N)) return HC_ERR_DEVICE;
@@ -482,6 +516,7 @@ int hc_create(int device_ordinal, hc_handle **out)
     const char *rpl = getenv("HYDROCOL_ROWS_PER_LAUNCH");
     if (rpl && atoi(rpl) > 0) h->rows_per_launch = atoi(rpl);
     if (const char *sg = getenv("HYDROCOL_STRICT_GUARD")) h->strict_guard = atoi(sg) != 0;
+    if (const char *po = getenv("HYDROCOL_POINT_ORDER")) h->fixed_order = strcmp(po, "fixed") == 0;
     if (const char *mi = getenv("HYDROCOL_DEBUG_MAX_ITER"))    // test hook: forces abandoned attempts
         if (atoi(mi) > 0) h->max_phase_iterations = atoi(mi);
     const char *jr = getenv("HYDROCOL_DEBUG_JAC_REJECT");   // test hook: exercises num_jac's retry branch
@@ -503,6 +538,7 @@ int hc_destroy(hc_handle *h)
     h->trace.release();
     h->gtab.release(); h->wtd_obs.release(); h->draw_idx.release(); h->stats.release(); h->scratch_i.release();
     h->Pdev.release(); h->iodev.release();
+    h->point_base.release(); h->point_order.release(); h->point_cost.release();
     h->daylight.release(); h->refresh.release(); h->wtd_u16.release(); h->moments.release(); h->counters.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -521,7 +557,8 @@ static int build_point(hc_handle *h, const hc_column_params *p, const double *no
         return fail(HC_ERR_ARG, "bad root-zone cell counts");
     if (!first && (D != h->p.dim_d || p->n_groups != h->p.n_groups || p->dz != h->p.dz))
         return fail(HC_ERR_ARG, "a parameter point must share dim_d, n_groups and dz with point 0");
-    if (p->flag_predict && p->sat_cells < 0) return fail(HC_ERR_ARG, "PREDICT mode: sat_cells < 0");
+    // low_lim = k - (sat_cells - 1) must stay inside the k-cell slice pde_fun sees: sat_cells >= 1
+    if (p->flag_predict && p->sat_cells < 1) return fail(HC_ERR_ARG, "PREDICT mode: sat_cells = %d, must be >= 1", p->sat_cells);
     ColumnDev P{};
     P.D = D; P.model = p->model; P.flag_et = p->flag_et; P.flag_lf = p->flag_lf; P.flag_hlift = p->flag_hlift;
     P.n_root_first = p->n_root_first; P.n_root_int = p->n_root_int; P.n_groups = p->n_groups;
@@ -535,7 +572,7 @@ static int build_point(hc_handle *h, const hc_column_params *p, const double *no
     // repaired PREDICT mode: low_lim = dim_d - (sat_cells - 1) of each pde_fun call as an int, nothing drains when
     // it is not positive (the reference's np.linspace(1.5, 0.0, low_lim) raises for a float or a negative count)
     P.flag_predict = p->flag_predict ? 1 : 0;
-    P.predict_low = std::max(0, (D - 2) - (p->sat_cells - 1));
+    P.predict_low = std::min(D - 2, std::max(0, (D - 2) - (p->sat_cells - 1)));
     P.predict_first = (1 - (p->sat_cells - 1)) >= 1 ? 1 : 0;
 
     const int M = D - 1, S = h->slots, cpl = h->cpl;
@@ -571,6 +608,7 @@ static int build_point(hc_handle *h, const hc_column_params *p, const double *no
     const bool special = (p->model == HC_MODEL_VRETTAS_FUNG && p->n == 2.0 && p->m == 0.5 && p->lambda_exp == 1.0);
     if (first) {
         h->P_host.clear(); h->tab_host.clear(); h->node_host.clear();
+        h->base_host.clear(); h->order_host.clear(); h->cost_total.clear();
         h->n_points = 0;
         h->p = *p;
         h->P = P;
@@ -805,8 +843,17 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
     a->kernel_ms = 0.0;
     a->launches = 0;
     int64_t fresh_consumed = 0;
+    // Per-row outputs are staged in device buffers of rows x members entries: a caller that asks for them gets shorter
+    // launches, so that the largest (psi_rows: 8 D bytes per member-row) stays within ~1 GiB however long the request.
+    int64_t out_bytes_per_row = 0;
+    if (a->psi_rows_out) out_bytes_per_row += N * (int64_t)D * 8;
+    if (a->stats_out) out_bytes_per_row += N * 6 * 4;
+    if (a->diag_out) out_bytes_per_row += N * 2 * 8;
+    if (a->wtd_out) out_bytes_per_row += N * 4;
+    const int64_t rows_cap = out_bytes_per_row > 0 ? std::max<int64_t>(1, (int64_t(1) << 30) / out_bytes_per_row) : INT32_MAX;
     for (int64_t done = 0; done < a->n_rows;) {
-        const int per_launch = h->rows_per_launch > 0 ? h->rows_per_launch : auto_rows_per_launch(N);
+        int per_launch = h->rows_per_launch > 0 ? h->rows_per_launch : auto_rows_per_launch(N);
+        if (h->rows_per_launch <= 0) per_launch = (int)std::min<int64_t>(per_launch, rows_cap);
         const int chunk = (int)std::min<int64_t>(per_launch, a->n_rows - done);
         const int64_t row0 = a->spinup ? a->row_begin : a->row_begin + done;
         int n_fresh = 0;
@@ -833,6 +880,11 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
         h->io_host.diag = a->diag_out ? h->diag.p : nullptr;
         rc = push_io(h);
         if (rc) return rc;
+        if (h->n_points > 1) {
+            HIP_TRY(hipMemcpyAsync(h->point_order.p, h->order_host.data(), (size_t)h->n_points * 4, hipMemcpyHostToDevice,
+                                   h->stream));
+            HIP_TRY(hipMemsetAsync(h->point_cost.p, 0, (size_t)h->n_points * 8, h->stream));
+        }
         HIP_TRY(hipEventRecord(h->ev0, h->stream));
         rc = launch_step(h, A);
         if (rc) return rc;
@@ -868,6 +920,15 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
         a->launches++;
         fresh_consumed += n_fresh;
         done += chunk;
+        if (h->n_points > 1 && !a->spinup) {
+            // what each point cost in this launch orders the next one: costliest point first (results do not depend on it)
+            std::vector<unsigned long long> cost((size_t)h->n_points);
+            HIP_TRY(hipMemcpy(cost.data(), h->point_cost.p, cost.size() * 8, hipMemcpyDeviceToHost));
+            for (int k = 0; k < h->n_points; k++) h->cost_total[(size_t)k] += cost[(size_t)k];
+            if (!h->fixed_order)
+                std::stable_sort(h->order_host.begin(), h->order_host.end(),
+                                 [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
+        }
     }
     unsigned long long cnt[4];
     HIP_TRY(hipMemcpy(cnt, h->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
@@ -1003,6 +1064,129 @@ int hc_reset_moments(hc_handle *h)
     HIP_TRY(hipSetDevice(h->device));
     h->moments_points = 0;
     return ensure_moments(h);
+}
+
+// The path's one collective without torch: a single process that drives several devices (one handle each) sums the
+// handles' moment tables over RCCL.  RCCL is bound at run time (dlopen), so the library loads on boxes without it and
+// a process that already carries an RCCL (torch's) keeps using that one.
+namespace {
+struct Rccl {
+    void *so = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+int load_rccl(Rccl &r)
+{
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.so) break;
+    }
+    if (!r.so) return fail(HC_ERR_UNSUPPORTED, "RCCL is not loadable (%s)", dlerror());
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.so, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.so, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.so, "ncclGroupEnd"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.so, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
+    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.AllReduce || !r.GetErrorString)
+        return fail(HC_ERR_UNSUPPORTED, "the RCCL library lacks an entry point this call needs");
+    return HC_OK;
+}
+}  // namespace
+
+int hc_allreduce_moments(hc_handle **handles, int n)
+{
+    if (!handles || n < 1 || n > 64) return fail(HC_ERR_ARG, "hc_allreduce_moments: bad argument");
+    size_t count = 0;
+    std::vector<int> devs((size_t)n);
+    for (int k = 0; k < n; k++) {
+        hc_handle *h = handles[k];
+        if (!h) return fail(HC_ERR_ARG, "handle %d is NULL", k);
+        HIP_TRY(hipSetDevice(h->device));
+        if (int rc = ensure_moments(h)) return rc;
+        const size_t c = (size_t)h->n_points * 3 * h->n_rows;
+        if (k == 0) count = c;
+        if (c != count) return fail(HC_ERR_ARG, "handle %d holds a moment table of another shape", k);
+        for (int j = 0; j < k; j++)
+            if (handles[j]->device == h->device) return fail(HC_ERR_ARG, "handles %d and %d share device %d: one handle per device", j, k, h->device);
+        devs[(size_t)k] = h->device;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    Rccl r;
+    if (int rc = load_rccl(r)) return rc;
+    constexpr int NCCL_INT64 = 4, NCCL_SUM = 0;     // rccl.h: ncclInt64, ncclSum
+    std::vector<void *> comms((size_t)n, nullptr);
+    int e = r.CommInitAll(comms.data(), n, devs.data());
+    if (e != 0) return fail(HC_ERR_DEVICE, "ncclCommInitAll failed: %s", r.GetErrorString(e));
+    int bad = 0;
+    bad = bad ? bad : r.GroupStart();
+    for (int k = 0; k < n && !bad; k++) {
+        (void)hipSetDevice(handles[k]->device);
+        bad = r.AllReduce(handles[k]->moments.p, handles[k]->moments.p, count, NCCL_INT64, NCCL_SUM, comms[(size_t)k],
+                          handles[k]->stream);
+    }
+    const int ge = r.GroupEnd();
+    bad = bad ? bad : ge;
+    hipError_t he = hipSuccess;
+    for (int k = 0; k < n; k++) {
+        (void)hipSetDevice(handles[k]->device);
+        const hipError_t e1 = hipStreamSynchronize(handles[k]->stream);
+        he = he == hipSuccess ? e1 : he;
+    }
+    for (int k = 0; k < n; k++) (void)r.CommDestroy(comms[(size_t)k]);
+    if (bad) return fail(HC_ERR_DEVICE, "RCCL all-reduce of the moment tables failed: %s", r.GetErrorString(bad));
+    HIP_TRY(he);
+    return HC_OK;
+}
+
+int hc_get_noise_scale(hc_handle *h, double *scale, int64_t first, int64_t count)
+{
+    if (!h || !scale || first < 0 || count < 0 || first + count > h->n_members || !h->nscale.p)
+        return fail(HC_ERR_ARG, "hc_get_noise_scale: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(scale, h->nscale.p + first, (size_t)count * 8, hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+
+int hc_set_noise_scale(hc_handle *h, const double *scale, int64_t first, int64_t count)
+{
+    if (!h || !scale || first < 0 || count < 0 || first + count > h->n_members || !h->nscale.p)
+        return fail(HC_ERR_ARG, "hc_set_noise_scale: bad argument");
+    if (!h->philox) return fail(HC_ERR_ARG, "hc_set_noise_scale: call hc_set_noise_philox first (it resets the scales to 1)");
+    for (int64_t k = 0; k < count; k++)
+        if (!(scale[k] > 0.0) || !(scale[k] <= 1.0))
+            return fail(HC_ERR_ARG, "noise scale %lld = %g is not a product of 0.8 factors in (0, 1]", (long long)(first + k), scale[k]);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(h->nscale.p + first, scale, (size_t)count * 8, hipMemcpyHostToDevice));
+    return HC_OK;
+}
+
+int hc_set_point_member_bases(hc_handle *h, const int64_t *base)
+{
+    if (!h) return fail(HC_ERR_ARG, "NULL handle");
+    if (!h->have_column) return fail(HC_ERR_ARG, "hc_set_column must come first");
+    h->base_host.clear();
+    if (base) {
+        for (int k = 0; k < h->n_points; k++)
+            if (base[k] < 0) return fail(HC_ERR_ARG, "member base of point %d is negative", k);
+        h->base_host.assign(base, base + h->n_points);
+    }
+    return HC_OK;
+}
+
+int hc_get_point_costs(hc_handle *h, uint64_t *cost)
+{
+    if (!h || !cost) return fail(HC_ERR_ARG, "hc_get_point_costs: bad argument");
+    if (!h->have_column) return fail(HC_ERR_ARG, "hc_set_column must come first");
+    for (int k = 0; k < h->n_points; k++)
+        cost[k] = (size_t)k < h->cost_total.size() ? h->cost_total[(size_t)k] : 0ull;
+    return HC_OK;
 }
 
 int hc_set_generic_exponents(hc_handle *h, int32_t on)

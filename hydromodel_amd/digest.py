@@ -18,6 +18,7 @@ device as plain arrays.  Reference anchors:
 """
 import json
 import math
+from functools import lru_cache
 from pathlib import Path
 
 import numpy as np
@@ -43,13 +44,18 @@ def interp_linear(xk, yk, x_new):
 
 
 def group_columns_tridiagonal(n):
-    """Column groups scipy uses for a tridiagonal ``jac_sparsity`` of size n.
+    """Column groups scipy uses for a tridiagonal ``jac_sparsity`` of size n (cached by n: a sweep builds one
+    ``ColumnTables`` per parameter point on the same grid).
 
     Restates ``group_columns(A, order=0)``: columns are visited in the order
     ``RandomState(0).permutation(n)``; a column joins the current group when it shares
     no row with the group's union (column j of a tridiagonal pattern has rows j-1..j+1).
     """
-    n = int(n)
+    return _group_columns_tridiagonal(int(n)).copy()
+
+
+@lru_cache(maxsize=16)
+def _group_columns_tridiagonal(n):
     order = np.random.RandomState(0).permutation(n)
     groups_p = -np.ones(n, dtype=np.int64)
     rows = [np.arange(max(c - 1, 0), min(c + 2, n)) for c in order]
@@ -127,13 +133,14 @@ class SoilProperties:
 
 
 def _water_content_rule(obj, name, value):
-    """Clip to [0, 1], then 0 <= res < min < max <= 1 must still hold (water_content.py:55-76, 88-190); a value that breaks
-    the ordering is refused and the old one kept."""
-    value = float(np.maximum(np.minimum(1.0, value), 0.0))
-    trial = {k: getattr(obj, "_" + k, None) for k in ("res", "min", "max")}
+    """Property setters of water_content.py:88-190: the new value is taken AS GIVEN (only the constructor clips to
+    [0, 1], :40-42); if 0 <= res < min < max <= 1 no longer holds the assignment is refused -- ValueError, old value
+    kept (the reference's own test: ``max += 1.0`` raises, code/tests/test_water_content.py:39-58)."""
+    trial = {k: getattr(obj, "_" + k) for k in ("res", "min", "max")}
     trial[name] = value
-    if None not in trial.values() and not (0.0 <= trial["res"] < trial["min"] < trial["max"] <= 1.0):
-        raise ValueError(f" {type(obj).__name__}: The volumetric water content input values are incorrect.")
+    if not (0.0 <= trial["res"] < trial["min"] < trial["max"] <= 1.0):
+        label = {"res": "residual", "min": "minimum", "max": "maximum"}[name]
+        raise ValueError(f" {type(obj).__name__}: The new {label}: {value} is not consistent with the rest of the values.")
     return value
 
 
@@ -174,6 +181,31 @@ class HydraulicConductivity:
         # the constructor clamps these two at zero (hydraulic_conductivity.py:56-57); only assignment raises
         self.sigma_noise = float(np.maximum(sigma_noise, 0.0))
         self.lambda_exponent = float(np.maximum(lambda_exponent, 0.0))
+
+
+# --------------------------------------------------------------------------- inverse retention curve
+SATURATION_CUT = 0.99998   # hydrological_model.py:103
+
+
+def inverse_retention(theta, porosity, theta_res, alpha, n, m, epsilon, dz):
+    """Water content -> pressure head, the inverse van Genuchten curve of ``HydrologicalModel.pressure_head``
+    (hydrological_model.py:43-119); the ONE implementation here, shared by the plugin objects (``models.py``) and the
+    spin-up start profile (``ensemble.pressure_head``).
+
+    ``theta`` and ``porosity`` broadcast against each other ([D] or [D, M]).  Effective saturation is clipped to
+    [epsilon, 1]; cells at or above ``SATURATION_CUT`` count as saturated and receive a hydrostatic ramp 0, dz, 2 dz, ...
+    in flattened (row-major) order of the saturated cells (:103,112); anything non-finite becomes -1e5 cm (:115).
+    Returns (psi, s_eff) with the shape of ``theta``."""
+    theta = np.asarray(theta, dtype=float)
+    span = porosity - theta_res
+    s_eff = np.clip((np.clip(theta, theta_res, porosity) - theta_res) / span, epsilon, 1.0)
+    wet = s_eff >= SATURATION_CUT
+    psi = np.zeros(theta.shape)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        psi[~wet] = -((s_eff[~wet] ** (-1.0 / m) - 1.0) ** (1.0 / n)) / alpha
+    psi[wet] = np.arange(0, np.count_nonzero(wet)) * dz
+    psi[~np.isfinite(psi)] = -1.0e+5
+    return psi, s_eff
 
 
 # --------------------------------------------------------------------------- static profiles

@@ -8,6 +8,7 @@ all-reduce of the per-row water-table moments (see :func:`allreduce_moments`).
 """
 import numpy as np
 
+from .digest import inverse_retention
 from .stepper import EnsembleStepper, moments_to_mean_std
 
 
@@ -22,18 +23,8 @@ def pressure_head(cols, theta):
         raise ValueError(f" HydrologicalModel: Input size dimensions don't match:"
                          f" {theta.shape[0]} not equal to {cols.dim_d}.")
     soil = cols.soil
-    eps = max(soil.epsilon, 1.0e-8)
-    por = cols.por_node
-    delta_s = por - cols.theta.res
-    q = np.minimum(np.maximum(theta, cols.theta.res), por)
-    s_eff = np.minimum(np.maximum((q - cols.theta.res) / delta_s, eps), 1.0)
-    id_sat = s_eff >= 0.99998
-    psi = np.zeros(theta.shape)
-    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
-        psi[~id_sat] = -((s_eff[~id_sat] ** (-1.0 / soil.m) - 1.0) ** (1.0 / soil.n)) / soil.alpha
-    psi[id_sat] = np.arange(0, np.sum(id_sat)) * cols.dz
-    psi[~np.isfinite(psi)] = -1.0e+5
-    return psi, s_eff
+    return inverse_retention(theta, cols.por_node, cols.theta.res, soil.alpha, soil.n, soil.m,
+                             max(soil.epsilon, 1.0e-8), cols.dz)
 
 
 def spinup_on_gpu(cols, forcing, n_rnd, device=0, burn_in=1500, flags=None, verbose=False, well_no=None):
@@ -187,6 +178,55 @@ class EnsembleSimulation:
         m = self.moments() if moments is None else moments
         return moments_to_mean_std(m, self.cols.dz, self.cols.z[0])
 
+    # -- checkpoint / resume (the single-column analogue in the reference is IC_Filename, simulation.py:358-385) ------
+    CHECKPOINT_KEYS = ("psi", "noise_scale", "moments", "next_row", "seed", "member_offset", "n_members", "dim_d",
+                       "dim_t", "initial_cond")
+
+    def dump(self, path):
+        """Everything a stopped Philox ensemble is defined by, in the results container (HDF5 through libhdf5, ``.npz``
+        where no libhdf5 loads): member states, per-member damping of the base noise vector, the moment table, the
+        next forcing row and the stream keys.  ``restore`` continues bit for bit."""
+        if self.noise != "philox":
+            raise ValueError(" EnsembleSimulation: dump/restore serves the Philox noise source "
+                             "(a NumPy stream's position is not part of the stepper).")
+        from pathlib import Path
+        from . import hdf5io
+        arrays = dict(psi=self.stepper.get_state(), noise_scale=self.stepper.noise_scale(),
+                      moments=np.asarray(self.stepper.moments()), next_row=np.array(self.next_row, dtype=np.int64),
+                      seed=np.array(self.seed, dtype=np.uint64), member_offset=np.array(self.member_offset, dtype=np.int64),
+                      n_members=np.array(self.n_members, dtype=np.int64), dim_d=np.array(self.cols.dim_d, dtype=np.int64),
+                      dim_t=np.array(self.forcing.dim_t, dtype=np.int64), initial_cond=np.asarray(self.psi0, dtype=float))
+        path = Path(path)
+        if hdf5io.available() and path.suffix != ".npz":
+            hdf5io.write(path, arrays)
+        else:
+            path = path.with_suffix(".npz")
+            np.savez(path, **arrays)
+        return path
+
+    @classmethod
+    def restore(cls, path, cols, forcing, device=0, flags=None):
+        """A new ensemble (new handle) continuing the one ``dump`` wrote: same members, same streams, same row."""
+        from pathlib import Path
+        from . import hdf5io
+        path = Path(path)
+        data = dict(np.load(path)) if path.suffix == ".npz" else hdf5io.read(path)
+        missing = [k for k in cls.CHECKPOINT_KEYS if k not in data]
+        if missing:
+            raise ValueError(f" EnsembleSimulation: {path} is not an ensemble checkpoint (missing {missing}).")
+        n, D, T = int(data["n_members"]), int(data["dim_d"]), int(data["dim_t"])
+        if D != cols.dim_d or T != forcing.dim_t:
+            raise ValueError(f" EnsembleSimulation: checkpoint of a [{D}]-node column over {T} rows does not fit "
+                             f"this run ([{cols.dim_d}], {forcing.dim_t}).")
+        psi = np.asarray(data["psi"], dtype=float).reshape(n, D)
+        sim = cls(cols, forcing, n, seed=int(data["seed"]), device=device, member_offset=int(data["member_offset"]),
+                  psi0=np.asarray(data["initial_cond"], dtype=float).reshape(-1)[:D], flags=flags)
+        sim.stepper.set_state(psi if n > 1 else psi[0])
+        sim.stepper.set_noise_scale(np.asarray(data["noise_scale"], dtype=float).reshape(n))
+        sim.stepper.set_moments(np.asarray(data["moments"], dtype=np.int64))
+        sim.next_row = int(data["next_row"])
+        return sim
+
     def close(self):
         self.stepper.close()
 
@@ -242,6 +282,29 @@ def merge_parameters(params, override):
     return p
 
 
+# What a parameter point may NOT change: the forcing digest (ET series, surface evaporation: simulation.py:273-352) is
+# built once from the base parameters and shared by every point of a sweep, and the PREDICT gate is taken on the base.
+SWEEP_SHARED_ENVIRONMENTAL = ("Atmospheric_Demand", "Wet_Season_pct", "Evaporation_pct")
+
+
+def check_sweep_points(params, points):
+    """Refuse parameter points that would silently run with the base point's forcing: an override of the
+    ``Environmental`` keys the forcing digest reads, of ``Simulation_Flags.PREDICT`` (the repair gate is taken once, on
+    the base), of the well or of the data file.  Returns the merged parameter dicts, one per point."""
+    merged = [merge_parameters(params, ov) for ov in points]
+    for k, mp in enumerate(merged):
+        for key in SWEEP_SHARED_ENVIRONMENTAL:
+            if mp["Environmental"].get(key) != params["Environmental"].get(key):
+                raise ValueError(f" Sweep: point {k} overrides Environmental.{key}; every point of a sweep shares the base "
+                                 f"forcing series (simulation.py:273-352) -- run such points as separate ensembles.")
+        if bool(mp["Simulation_Flags"].get("PREDICT", False)) != bool(params["Simulation_Flags"].get("PREDICT", False)):
+            raise ValueError(f" Sweep: point {k} overrides Simulation_Flags.PREDICT; the flag is taken from the base parameters.")
+        for key in ("Well_No", "Site_Information", "Data_Filename"):
+            if mp.get(key) != params.get(key):
+                raise ValueError(f" Sweep: point {k} overrides {key}; every point shares the well and the forcing file.")
+    return merged
+
+
 class SweepSimulation:
     """BASELINE config 5: P parameter points x ``n_members`` stochastic members each, ALL in one handle and one
     launch per batch of rows (``hc_add_point``): per-member parameter point -> its own column parameters and slot
@@ -254,11 +317,19 @@ class SweepSimulation:
     together in one ``hc_spinup`` launch (one member per point, that point's lead member's spin-up vector), and the
     result is broadcast to the point's members."""
 
-    def __init__(self, cols_list, forcing, n_members, seed=0, device=0, first_point=0, flags=None, psi0=None):
+    def __init__(self, cols_list, forcing, n_members, seed=0, device=0, first_point=0, flags=None, psi0=None,
+                 point_ids=None):
         self.points = list(cols_list)
         self.P, self.n = len(self.points), int(n_members)
         self.forcing, self.seed, self.device = forcing, int(seed), device
-        self.member_offset = int(first_point) * self.n
+        # global index of each of this handle's points in the whole sweep: consecutive from `first_point`, or any
+        # list (`point_ids`) when points are dealt to ranks round-robin so that every rank gets the same mix of costs
+        self.point_ids = (np.arange(self.P, dtype=np.int64) + int(first_point) if point_ids is None
+                          else np.asarray(point_ids, dtype=np.int64))
+        if self.point_ids.shape != (self.P,) or np.unique(self.point_ids).size != self.P or self.point_ids.min() < 0:
+            raise ValueError(" SweepSimulation: point_ids must name each of the handle's points once.")
+        self.bases = self.point_ids * self.n
+        self.member_offset = int(self.bases[0])
         cols = self.points[0]
         self.cols = cols
         self.spinup_iters = None
@@ -271,6 +342,8 @@ class SweepSimulation:
         self.stepper.set_generic_exponents(True)
         self.stepper.set_state(self.psi0 if self.P > 1 else self.psi0[0])
         self.stepper.set_noise_philox(self.seed, self.member_offset)
+        if self.P > 1:
+            self.stepper.set_point_member_bases(self.bases)
         self.next_row, self.kernel_ms, self.launches = 1, 0.0, 0
 
     def _spinup(self, flags):
@@ -279,8 +352,7 @@ class SweepSimulation:
         try:
             lead.set_generic_exponents(True)
             lead.set_noise_philox(self.seed, 0)
-            noise = np.stack([lead.philox_normals(self.member_offset + j * self.n, PHILOX_DRAW_SPINUP)
-                              for j in range(P)])
+            noise = np.stack([lead.philox_normals(int(self.bases[j]), PHILOX_DRAW_SPINUP) for j in range(P)])
             start = np.stack([pressure_head(c, c.por_raw)[0] for c in self.points])
             lead.set_state(start if P > 1 else start[0])
             lead.set_noise_host(noise)
@@ -304,29 +376,36 @@ class SweepSimulation:
         self.stepper.close()
 
 
+def deal_points(n_points, rank, world):
+    """Global indices of the parameter points rank `rank` of `world` runs: round-robin."""
+    return list(range(int(rank), int(n_points), int(world)))
+
+
 def parameter_sweep(params, data, well, points, n_members, n_rows, seed=0, device=0, rank=0, world=1,
                     one_launch=True, rows_per_call=48 * 8):
     """BASELINE config 5: a grid of (n, a0, psi_sat, ...) points x ``n_members`` realisations each.
 
     ``points`` is a list of dicts ``{"Soil_Properties": {...}, "Hydraulic_Conductivity": {...}, ...}`` merged over
-    ``params``; every point gets its own tables and its own spin-up.  Contiguous blocks of whole points are dealt to
-    ranks (rank r owns points [r P / world, (r + 1) P / world)), with no communication.  ``one_launch`` (default)
+    ``params``; every point gets its own tables and its own spin-up.  Whole points are dealt to ranks round-robin
+    (:func:`deal_points`: rank r owns points r, r + world, ... -- a grid's cost grows along its slowest axis, so
+    contiguous blocks would hand one rank all the expensive points), with no communication; a point's members keep
+    their global ids (point k owns members [k n, (k + 1) n) of the Philox stream) whoever runs it.  ``one_launch`` (default)
     steps all of a rank's points in one handle (:class:`SweepSimulation`); ``one_launch=False`` runs them one after
     another, one handle each -- same global member ids, bit-identical results, kept as the cross-check.
     Returns {point index: {"moments", "wtd_mean_cm", "wtd_std_cm", "psi0"}}.
     """
     from .digest import ColumnTables, ForcingDigest
     P = len(points)
-    lo, hi = (rank * P) // world, ((rank + 1) * P) // world
-    mine = list(range(lo, hi))
+    mine = deal_points(P, rank, world)
     if not mine:
         return {}
-    cols_all = [ColumnTables(merge_parameters(params, points[k]), well) for k in mine]
+    merged = check_sweep_points(params, points)
+    cols_all = [ColumnTables(merged[k], well) for k in mine]
     forcing = ForcingDigest(params, data, cols_all[0])
-    groups = [(lo, cols_all)] if one_launch else [(k, [c]) for k, c in zip(mine, cols_all)]
+    groups = [(mine, cols_all)] if one_launch else [([k], [c]) for k, c in zip(mine, cols_all)]
     out = {}
-    for first, cols_list in groups:
-        sim = SweepSimulation(cols_list, forcing, n_members, seed=seed, device=device, first_point=first)
+    for ids, cols_list in groups:
+        sim = SweepSimulation(cols_list, forcing, n_members, seed=seed, device=device, point_ids=ids)
         done = 0
         while done < n_rows:
             n = min(rows_per_call, n_rows - done)
@@ -335,7 +414,7 @@ def parameter_sweep(params, data, well, points, n_members, n_rows, seed=0, devic
         m = sim.moments()
         for j, c in enumerate(cols_list):
             mean_cm, std_cm = moments_to_mean_std(m[j], c.dz, c.z[0])
-            out[first + j] = {"moments": m[j], "wtd_mean_cm": mean_cm, "wtd_std_cm": std_cm, "psi0": sim.psi0[j],
+            out[ids[j]] = {"moments": m[j], "wtd_mean_cm": mean_cm, "wtd_std_cm": std_cm, "psi0": sim.psi0[j],
                               "spinup_iterations": None if sim.spinup_iters is None else int(sim.spinup_iters[j]),
                               "kernel_ms": sim.kernel_ms}
         sim.close()

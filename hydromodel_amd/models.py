@@ -18,7 +18,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from .digest import (MODEL_VAN_GENUCHTEN, MODEL_VRETTAS_FUNG, interp_linear, layer_tables, porosity_profiles)
+from .digest import (MODEL_VAN_GENUCHTEN, MODEL_VRETTAS_FUNG, interp_linear, inverse_retention, layer_tables,
+                     porosity_profiles)
 
 
 class Porosity(object):
@@ -78,20 +79,10 @@ class HydrologicalModel(object):
     def pressure_head(self, theta, z):
         """Inverse van Genuchten, ``hydrological_model.py:43-119``: returns (psi, s_eff)."""
         z, theta, dim_d, dim_m = self._check(theta, z)
-        porous_z, *_ = self.porous(z)
-        porous_z = np.atleast_1d(porous_z)
+        porous_z = np.atleast_1d(self.porous(z)[0])
         if dim_m is not None:
-            porous_z = porous_z.repeat(dim_m).reshape(dim_d, dim_m)
-        delta_s = porous_z - self.theta_res
-        q = np.minimum(np.maximum(theta, self.theta_res), porous_z)
-        s_eff = np.minimum(np.maximum((q - self.theta_res) / delta_s, self.epsilon), 1.0)
-        id_sat = s_eff >= 0.99998
-        psi_z = np.zeros(theta.shape)
-        with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
-            psi_z[~id_sat] = -((s_eff[~id_sat] ** (-1.0 / self.m) - 1.0) ** (1.0 / self.n)) / self.alpha
-        psi_z[id_sat] = np.arange(0, np.sum(id_sat)) * self.dz
-        psi_z[~np.isfinite(psi_z)] = -1.0e+5
-        return psi_z, s_eff
+            porous_z = porous_z[:, None]               # one porosity per depth, shared by the M columns
+        return inverse_retention(theta, porous_z, self.theta_res, self.alpha, self.n, self.m, self.epsilon, self.dz)
 
     # -- the plugin call on the device ---------------------------------------------------
     def _params(self):

@@ -189,12 +189,37 @@ class EnsembleStepper:
             raise ValueError(f"moments must hold {self.P} x [3, {self.T}] values")
         L.check(self.lib.hc_set_moments(self.h, L.lptr(m)))
 
+    def noise_scale(self, first=0, count=None):
+        """Per-member damping of the Philox base vector, 0.8^(failed attempts on non-refresh rows) (richards_pde.py:522)."""
+        count = self.N - first if count is None else count
+        out = np.empty(count)
+        L.check(self.lib.hc_get_noise_scale(self.h, L.dptr(out), int(first), int(count)))
+        return out
+
+    def set_noise_scale(self, scale, first=0):
+        scale = L.as_f64(scale)
+        L.check(self.lib.hc_set_noise_scale(self.h, L.dptr(scale), int(first), int(scale.size)))
+
+    def set_point_member_bases(self, bases):
+        """Global id of each parameter point's first member (Philox key of member j of point k = bases[k] + j)."""
+        bases = np.ascontiguousarray(bases, dtype=np.int64)
+        if bases.shape != (self.P,):
+            raise ValueError(f"need one member base per parameter point ({self.P})")
+        L.check(self.lib.hc_set_point_member_bases(self.h, L.lptr(bases)))
+
+    def point_costs(self):
+        """RHS evaluations spent on each parameter point's members so far ([P]; zeros for a single point)."""
+        out = (C.c_uint64 * self.P)()
+        L.check(self.lib.hc_get_point_costs(self.h, out))
+        return np.array(list(out), dtype=np.uint64)
+
     def set_generic_exponents(self, on=True):
         """Pin the generic-exponent cell model (include/hydrocol.h): same bits for a point alone or inside a sweep."""
         L.check(self.lib.hc_set_generic_exponents(self.h, int(bool(on))))
 
     def set_rows_per_launch(self, rows):
-        """Rows per kernel launch (default 48); long launches suit small ensembles (include/hydrocol.h)."""
+        """Rows per kernel launch; 0 = the library's choice (48 = one simulated day for >= 65 536 members, proportionally
+        more for smaller ensembles, at most a year; shorter when per-row outputs are requested -- include/hydrocol.h)."""
         L.check(self.lib.hc_set_rows_per_launch(self.h, int(rows)))
 
     def set_iteration_budget(self, phase_steps):
@@ -241,3 +266,12 @@ def moments_to_mean_std(moments, dz, z0=0.0):
         mean_idx = moments[..., 1, :] / cnt
         var_idx = np.maximum(moments[..., 2, :] / cnt - mean_idx ** 2, 0.0)
     return z0 + dz * mean_idx, dz * np.sqrt(var_idx)
+
+
+def allreduce_handles(steppers):
+    """``hc_allreduce_moments``: one process, several devices, one stepper each -- every stepper's moment table becomes
+    the sum over all of them (RCCL inside the library, no torch involved)."""
+    lib = L.load()
+    arr = (C.c_void_p * len(steppers))(*[st.h for st in steppers])
+    L.check(lib.hc_allreduce_moments(arr, len(steppers)))
+

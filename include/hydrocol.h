@@ -198,6 +198,31 @@ int hc_export_moments(hc_handle *h, void *device_dst);
 int hc_set_moments(hc_handle *h, const int64_t *moments);
 int hc_reset_moments(hc_handle *h);
 
+/* The path's one collective inside the library, for a single process that drives several devices with
+ * one handle each: every handle's moment table is replaced by the sum over all n handles (ncclAllReduce, ncclInt64,
+ * ncclSum over RCCL / xGMI, in place on device memory, on the handles' own streams).  Integer sums: the result does not
+ * depend on the number of devices.  RCCL is bound at run time (dlopen); HC_ERR_UNSUPPORTED when it is not loadable.
+ * One process per GPU (torch.distributed) callers use hc_export_moments + their own all-reduce instead. */
+int hc_allreduce_moments(hc_handle **handles, int n);
+
+/* Bit-exact resume of a Philox ensemble (the reference's single-column analogue is IC_Filename,
+ * src/simulation.py:358-385): besides the state (hc_get_state / hc_set_state), the moment table (hc_get_moments /
+ * hc_set_moments) and the next row, a stopped ensemble is defined by the damping every member's base noise vector has
+ * collected from failed attempts, scale[member] = 0.8^k (src/richards_pde.py:522 applied to the base vector).
+ * hc_set_noise_scale must follow hc_set_noise_philox (which resets the scales to 1); values must lie in (0, 1]. */
+int hc_get_noise_scale(hc_handle *h, double *scale, int64_t first_member, int64_t count);
+int hc_set_noise_scale(hc_handle *h, const double *scale, int64_t first_member, int64_t count);
+
+/* Several parameter points in one handle: base[k] = global id of point k's first member, i.e. the Philox stream of
+ * member j of point k is keyed by base[k] + j.  Default (and base = NULL): member_offset + k * members_per_point, the
+ * points of this handle are consecutive points of the sweep.  A rank that is dealt non-consecutive points (round-robin
+ * by cost) sets the bases so that a point's realisations do not depend on who runs it. */
+int hc_set_point_member_bases(hc_handle *h, const int64_t *base);
+/* cost[n_points]: RHS evaluations spent on each point's members by hc_step_rows since the points were installed (zeros
+ * for a single point).  The library walks the points costliest-first from the second launch on (the order changes
+ * no result; HYDROCOL_POINT_ORDER=fixed in the environment at hc_create keeps point order). */
+int hc_get_point_costs(hc_handle *h, uint64_t *cost);
+
 /* Test hooks -------------------------------------------------------------------------- */
 /* dydt for every member's current state on forcing row `row` (noise = base vectors).
  * aux (nullable): [n_members][3*(D-1)+1] = c | s | f at the midpoints, then pL. */

@@ -291,6 +291,7 @@ static void pde_fun(const ho_column *c, const ho_row *r, int view, const double 
              * it passes, ValueError for a negative one, which the single-cell first call would hit). */
             double alpha_low = r->wet ? -2.5e-3 : -1.5e-3;
             int low_lim = k - (c->sat_cells - 1);
+            if (low_lim > k) low_lim = k;   /* sat_cells <= 0 (refused by the Python face): never beyond the slice */
             if (low_lim > 0 && wtd_est < low_lim) {
                 int j = wtd_est;
                 /* numpy.linspace: step = (stop - start) / (num - 1); y = arange(num) * step + start; y[-1] = stop */

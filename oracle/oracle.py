@@ -119,6 +119,8 @@ class Oracle:
         c.groups = self._groups.ctypes.data_as(_ip)
         # repaired PREDICT mode: an extension, pinned by nothing but its own formula (hydro_oracle.h)
         c.flag_predict, c.sat_cells = int(bool(fl.get("PREDICT"))), int(cols.sat_cells)
+        if c.flag_predict and c.sat_cells < 1:
+            raise ValueError("PREDICT mode needs sat_cells >= 1 (low_lim = k - (sat_cells - 1) must stay inside the slice)")
         self.c = c
         self.D = cols.dim_d
 

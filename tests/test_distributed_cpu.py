@@ -47,3 +47,40 @@ def test_moments_allreduce_world2_is_exact(tmp_path):
 def test_allreduce_is_identity_without_process_group():
     m = np.arange(12, dtype=np.int64).reshape(3, 4)
     assert allreduce_moments(m, torch.device("cpu")) is m
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher around it: the parent starts two ranks itself.
+    --probe-ranks stops after the process group is up, so this runs on the CPU box over gloo."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--probe-ranks"], cwd=repo,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["ranks_counted"] == 2 and out["backend"] == "gloo"
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--probe-ranks"], cwd=repo, env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_points_are_dealt_round_robin():
+    from hydromodel_amd.ensemble import deal_points
+    parts = [deal_points(512, r, 8) for r in range(8)]
+    assert sorted(sum(parts, [])) == list(range(512)) and all(len(p) == 64 for p in parts)
+    assert parts[3][:3] == [3, 11, 19]
+    assert deal_points(3, 5, 8) == []

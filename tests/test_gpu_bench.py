@@ -23,10 +23,14 @@ def _run(cmd, timeout=600):
 
 def test_bench_contract_one_rank():
     out = _run([sys.executable, "bench.py", "--members", "4096", "--steps", "2", "--warmup", "1", "--cpu-seconds", "4",
-                "--sustained-members", "2048", "--sustained-days", "3"])
+                "--sustained-members", "2048", "--sustained-days", "3", "--heavy-members", "1024", "--heavy-days", "2"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sustained"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sustained", "sustained_heavy",
+                "ranks", "backend"):
         assert key in out, key
+    assert out["ranks"] == 1 and out["members_in_reduced_moments"] == 4096
+    hv = out["sustained_heavy"]
+    assert hv["members"] == 1024 and hv["days"] == 2 and hv["value"] > 1e3 and "1-year" in hv["workload"]
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["dtype"] == "f64"
     assert out["unit"] == "column-days/s" and out["value"] > 1e4 and out["vs_baseline"] is None
     r = out["roofline"]
@@ -45,10 +49,13 @@ def test_bench_contract_one_rank():
 
 
 def test_bench_two_ranks_share_the_moments():
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                "--master-addr", "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "2", "--backend", "gloo",
+    """The driver's spelling, `python bench.py --gpus 2 ...` with NO launcher around it: bench.py starts the two ranks
+    itself (they share the one card here, over gloo; RCCL needs one GPU per rank)."""
+    two = _run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo",
                 "--members", "2048", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
-    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["cpu_baseline"] is None and two["sustained"] is None
+    assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["backend"] == "gloo"
+    assert two["scaling"] == "weak" and two["cpu_baseline"] is None and two["sustained"] is None
+    assert two["members_in_reduced_moments"] == 4096
     # whole-job aggregate: both ranks' members over the max-over-ranks time
     assert abs(two["value"] - 2 * 2048 * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-6 * two["value"]
     one = _run([sys.executable, "bench.py", "--members", "4096", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
@@ -56,3 +63,44 @@ def test_bench_two_ranks_share_the_moments():
     # members are keyed by their global id: 2 x 2048 sharded == 4096 on one rank, to the last bit of the statistics
     assert two["wtd_mean_cm_last_row"] == one["wtd_mean_cm_last_row"]
     assert two["wtd_std_cm_last_row"] == one["wtd_std_cm_last_row"]
+
+
+def test_bench_under_a_launcher_still_works():
+    """... and the pre-launched spelling of the contract (`python -m torch.distributed.run ... bench.py --gpus 2`)."""
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "2", "--backend", "gloo",
+                "--members", "1024", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["members_in_reduced_moments"] == 2048
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--members", "1024", "--steps", "1"], cwd=REPO, env=env,
+                       capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the RCCL launch is legitimate here")
+    assert p.returncode != 0 and "RCCL ranks need" in (p.stderr + p.stdout)
+
+
+def test_bench_sweep_workload_contract():
+    """--workload sweep (BASELINE configs[4]) at a reduced size: same JSON contract, the generic kernel, the per-point
+    census; two gloo ranks deal the points round-robin and cover the grid once."""
+    one = _run([sys.executable, "bench.py", "--workload", "sweep", "--points", "8", "--members", "256", "--steps", "1",
+                "--warmup", "1"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sweep_rank0"):
+        assert key in one, key
+    assert one["scaling"] == "strong" and one["config"]["points"] == 8 and one["config"]["points_per_gpu"] == 8
+    r = one["roofline"]
+    assert r["algorithmic_bytes_per_launch"] == 8 * 256 * 48 * (16 * 300 + 16)
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    sw = one["sweep_rank0"]
+    assert sw["spinup_capped"] == 0 and len(sw["costliest_points"]) == 5
+    lo, mid, hi = sw["rhs_evaluations_per_column_step_min_median_max"]
+    assert 5.0 < lo <= mid <= hi
+    two = _run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--workload", "sweep", "--points", "8",
+                "--members", "256", "--steps", "1", "--warmup", "1"])
+    assert two["n_gpus"] == 2 and two["config"]["points_per_gpu"] == 4
+    assert abs(two["value"] - 8 * 256 / (two["ms_per_step"] * 1e-3)) < 1e-6 * two["value"]
+

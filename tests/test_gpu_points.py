@@ -17,7 +17,8 @@ TAGS = sorted(points())
 @pytest.fixture(scope="module")
 def gpu():
     import torch
-    assert torch.cuda.is_available(), "these tests need a GPU"
+    if not torch.cuda.is_available():
+        pytest.skip("these tests need a GPU")
     import __graft_entry__ as ge
     ge.build()
     from hydromodel_amd import stepper

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu():
     import torch
-    assert torch.cuda.is_available(), "these tests need a GPU"
+    if not torch.cuda.is_available():
+        pytest.skip("these tests need a GPU")
     import __graft_entry__ as ge
     ge.build()
     from hydromodel_amd import stepper
@@ -217,8 +218,6 @@ def test_rows_in_one_launch_equal_rows_launched_one_by_one_with_philox_noise(gpu
     once passed every host-noise test and differed here from the second row on (DESIGN.md §5 "Deep columns")."""
     from hydromodel_amd.digest import ColumnTables, ForcingDigest
     from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
-    if build != "special" and dim_d in (361, 461, 541):
-        pytest.skip("generic / PREDICT builds: one depth per group of cells-per-lane variants")
     params = default_parameters()
     if build == "predict":
         params["Simulation_Flags"]["PREDICT"] = True

@@ -1,0 +1,321 @@
+"""Round-3 GPU checks: every G4 state straight against the reference's solve, the whole year side by side (reference /
+oracle / GPU), BASELINE config 5 at its full size, bit-exact ensemble resume, the in-library RCCL all-reduce."""
+import copy
+
+import numpy as np
+import pytest
+
+from helpers import WELLS, digest, forcing_frame, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("these tests need a GPU")
+    import __graft_entry__ as ge
+    ge.build()
+    from hydromodel_amd import stepper
+    return stepper
+
+
+def forcing_with_row(forcing, row, precip, atm, daylight, wtd_obs):
+    """A copy of the digest whose row `row` carries the given arguments (the golden states were evaluated with
+    explicit (hour, precip, atm, wtd) rather than a row of the synthetic forcing); never a refresh row."""
+    f = copy.copy(forcing)
+    for name in ("precip", "atm", "daylight", "wtd_obs", "refresh", "wet_season"):
+        setattr(f, name, np.array(getattr(forcing, name)))
+    f.precip[row], f.atm[row], f.daylight[row], f.wtd_obs[row], f.refresh[row] = precip, atm, int(daylight), wtd_obs, 0
+    return f
+
+
+@pytest.mark.parametrize("well", [1, 200, 300])
+def test_every_constructed_state_matches_the_reference_solve(gpu, well):
+    """G4 on the GPU directly against the reference: all 13 constructed states the reference
+    solved in one attempt (the 14th, HLIFT at night, takes > 1 000 RHS evaluations and is chaotic: the CPU suite skips it
+    too) x 3 wells, `RichardsPDE.solve` over t_span (7, 8) (richards_pde.py:478-537) -> forcing row 8 carrying the
+    state's own (hour, precip, atm, wtd) arguments and flags.  Tiers: a regular row (<= 100 RHS evaluations) must
+    reproduce the reference's nfev/njev/nlu/steps and agree to 1e-6 (1 + |psi|); stiff constructed states
+    (~200 evaluations, ~75 steps, Jacobian refreshed up to 10 times) decorrelate in the last bits of the FD Jacobian
+    and are held to the integrator's accuracy class, 5e-2 (1 + |psi|)  (DESIGN.md §3)."""
+    _, cols, forcing = digest(well)
+    g = golden(f"g34_states_{well}.npz")
+    tiers = {"<1e-9": 0, "<1e-6": 0, "stiff <5e-2": 0}
+    same = total = regular = 0
+    for name in g["names"]:
+        name = str(name)
+        ref_stats = g[f"{name}_solve_stats"]
+        if name == "hlift_night" or ref_stats.shape[0] != 1:
+            continue
+        fl = g[f"{name}_flags"]
+        hour = int(g[f"{name}_hour"])
+        f8 = forcing_with_row(forcing, 8, float(g[f"{name}_precip"]), float(g[f"{name}_atm"]), 6 <= hour <= 17,
+                              int(g["wtd_idx"]))
+        st = gpu.EnsembleStepper(cols, f8, 1, flags={"ET": bool(fl[1]), "LF": bool(fl[2]), "HLIFT": bool(fl[3])})
+        st.set_state(g[f"{name}_y"][None, :])
+        st.set_noise_host(g["n_rnd"][None, :])
+        out = st.step_rows(8, 1, fresh_noise=np.zeros((0,)), spinup=bool(fl[0]), moments=False, want_stats=True)
+        y1 = st.get_state()[0]
+        noise_after = st.get_noise_base()[0]
+        st.close()
+        ry = g[f"{name}_solve_y"]
+        err = float(np.max(np.abs(y1 - ry) / (1 + np.abs(ry))))
+        is_regular = int(ref_stats[0, 0]) <= 100
+        got = out["stats"][0, 0, :5].tolist()
+        total += 1
+        regular += is_regular
+        same += got == ref_stats[0, :5].tolist()
+        tiers["<1e-9" if err < 1e-9 else ("<1e-6" if err < 1e-6 else "stiff <5e-2")] += 1
+        assert got[4] == 1 and np.array_equal(noise_after, g[f"{name}_solve_nrnd_after"]), name     # one attempt, noise untouched
+        if is_regular:
+            assert err < 1e-6 and got == ref_stats[0, :5].tolist(), (well, name, err, got, ref_stats[0])
+        else:
+            assert err < 5e-2, (well, name, err, got, ref_stats[0])
+    print(f"[well {well}] G4 on the GPU vs the reference's solves: {same}/{total} states with the reference's "
+          f"nfev/njev/nlu/steps/attempts ({regular} regular, all of them exact); error tiers {tiers}")
+    assert total == 13 and same >= regular
+
+
+def test_whole_year_reference_oracle_and_gpu_side_by_side(gpu):
+    """The reference's year (G5, well 1, seed 911) against the C oracle AND the GPU, both free-running from the
+    reference's initial condition on the reference's own noise stream (default_rng(SeedSequence(911)): draw #0 spin-up,
+    #1 base, one per refresh row -- simulation.py:426,561,601): water-table index on all 17 519 solved rows.  The rows on
+    which the solver gives up (x0.8 damping, richards_pde.py:522) are chaotic events that land on different rows in the
+    three implementations and rescale the base noise for the rest of the year, so equality decays over the year in
+    each pair; nobody is ever more than one 5-cm cell from the reference."""
+    from oracle.oracle import Oracle
+    _, cols, forcing = digest(1)
+    g = golden("g5_traj_1.npz")
+    D, T = cols.dim_d, forcing.dim_t
+    rng = np.random.default_rng(np.random.SeedSequence(911))
+    rng.standard_normal(D)
+    base = rng.standard_normal(D)
+    n_ref = int(forcing.refresh.sum())
+    fresh = np.array([rng.standard_normal(D) for _ in range(n_ref)])
+    ref_idx = np.rint(g["wtd_est_cm"] / cols.dz).astype(int)
+    o = Oracle(cols, forcing.surface_evap)
+    r = o.run(forcing, g["initial_cond"], base, fresh, 1, T, want_stats=True)
+    st = gpu.EnsembleStepper(cols, forcing, 1)
+    st.set_state(g["initial_cond"])
+    st.set_noise_host(base[None, :])
+    out = st.step_rows(1, T - 1, fresh_noise=fresh[:, None, :], want_wtd=True, want_stats=True)
+    st.close()
+    gpu_idx, orc_idx = out["wtd"][:, 0], r["wtd_est"][1:]
+    d_gr, d_or, d_go = (np.abs(a - b) for a, b in ((gpu_idx, ref_idx[1:]), (orc_idx, ref_idx[1:]), (gpu_idx, orc_idx)))
+    retried = {"reference": int((g["per_row_stats"][:, 4] > 1).sum()), "oracle": int((r["per_row"][:, 4] > 1).sum()),
+               "gpu": int((out["stats"][:, 0, 4] > 1).sum())}
+    print(f"whole year, water-table index equal on: GPU vs reference {(d_gr == 0).mean():.1%}, oracle vs reference "
+          f"{(d_or == 0).mean():.1%}, GPU vs oracle {(d_go == 0).mean():.1%} of {d_gr.size} rows; max distance "
+          f"{d_gr.max()} / {d_or.max()} / {d_go.max()} cells; rows that needed a retry: {retried}")
+    assert d_gr.max() <= 1 and d_or.max() <= 1 and d_go.max() <= 1
+    assert (d_gr[:1400] == 0).mean() > 0.98 and (d_or[:1400] == 0).mean() > 0.98
+    assert (d_or == 0).mean() >= 0.95            # measured 97.2 %
+    assert (d_gr == 0).mean() >= 0.90            # SURVEY §8c asked for >= 99 %: not reachable for ANY implementation
+    assert (d_go == 0).mean() >= 0.90            # once the retry rows differ (see the docstring); DESIGN.md §3
+
+
+def _sweep_points(k=8):
+    return [{"Soil_Properties": {"n": float(n), "a0": float(a0), "psi_sat": float(ps)}}
+            for n in np.linspace(1.5, 3.0, k) for a0 in np.geomspace(0.003, 0.03, k) for ps in -np.geomspace(1e-3, 1.0, k)]
+
+
+def test_config5_at_full_size_in_one_handle(gpu):
+    """BASELINE configs[4] at its size (VERDICT r2 missing 2): the 8 x 8 x 8 (n, a0, psi_sat) grid of SURVEY.md §8d x
+    4 096 members x D = 300 in ONE handle (5 GB of state), every point from its own spin-up, one simulated day in one
+    launch.  Size-independent properties: every point counts 4 096 members on every row; three points spread over the
+    grid are bit-equal -- states and moments -- to stand-alone handles running the same global member ids; members of
+    two points (one mild, one from the costly corner) agree with the CPU ORACLE fed the same Philox normals, so the
+    multi-point launch is checked against something other than itself."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import PHILOX_DRAW_SPINUP, SweepSimulation, check_sweep_points
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    from oracle.oracle import Oracle
+    params = default_parameters()
+    merged = check_sweep_points(params, _sweep_points())
+    well = synthetic_well(300)
+    cols_all = [ColumnTables(mp, well) for mp in merged]
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols_all[0])
+    P, M, D, rows = len(cols_all), 4096, 300, 48
+    assert P == 512
+    big = SweepSimulation(cols_all, forcing, M, seed=17)
+    assert (np.asarray(big.spinup_iters) > 0).all()                      # every spin-up met its stop rule
+    big.advance(rows)
+    m = big.moments()
+    assert m.shape == (P, 3, forcing.dim_t)
+    assert np.array_equal(m[:, 0, 1:1 + rows], np.full((P, rows), M))
+    assert (m[:, 0, 1 + rows:] == 0).all() and (m[:, 0, 0] == 0).all()
+    cost = big.stepper.point_costs()
+    assert cost.shape == (P,) and (cost >= M * rows * 8).all()            # >= 8 RHS evaluations per column-step everywhere
+    cnt = big.stepper.counters()
+    windows = (3, 260, 509)
+    states = {j: big.stepper.get_state(j * M, M) for j in windows}
+    checks = {j: big.stepper.get_state(j * M, 2) for j in (219, 405)}
+    psi0 = big.psi0.copy()
+    big.close()
+    for j in windows:
+        assert np.isfinite(states[j]).all()
+        one = SweepSimulation([cols_all[j]], forcing, M, seed=17, first_point=j, psi0=psi0[j])
+        one.advance(rows)
+        assert np.array_equal(one.stepper.get_state(), states[j]), j
+        assert np.array_equal(one.moments()[0], m[j]), j
+        one.close()
+    # the multi-point launch against the oracle: members 0 and 1 of two points, fed the Philox normals the kernel drew
+    worst = 0.0
+    for j in (219, 405):                                   # (n, a0, psi_sat) = (2.14, 0.008, -0.019) and (2.79, 0.006, -0.14)
+        c = cols_all[j]
+        o = Oracle(c, forcing.surface_evap)
+        probe = gpu.EnsembleStepper(c, forcing, 1)
+        probe.set_noise_philox(17, 0)
+        n_fresh = int(forcing.refresh[1:1 + rows].sum())
+        for k in range(2):
+            gid = j * M + k
+            base = probe.philox_normals(gid, 0)
+            fresh = np.stack([probe.philox_normals(gid, q + 1) for q in range(n_fresh)]) if n_fresh else np.zeros((0, D))
+            r = o.run(forcing, psi0[j], base, fresh, 1, 1 + rows)
+            e = float(np.max(np.abs(checks[j][k] - r["psi"]) / (1 + np.abs(r["psi"]))))
+            worst = max(worst, e)
+            # 48 chained rows through the generic-exponent cell model (in-house exp/log against the oracle's libm pow)
+            assert e < 5e-3, (j, k, e)
+        probe.close()
+    print(f"config 5 at full size: 512 x 4096 x D=300, one day in one launch; failed attempts {cnt['failed_attempts']}, "
+          f"guard trips {cnt['guard_trips']}; RHS evaluations per column-step by point: min {cost.min() / (M * rows):.1f} "
+          f"median {np.median(cost) / (M * rows):.1f} max {cost.max() / (M * rows):.1f}; worst member vs the oracle after "
+          f"48 rows {worst:.2e}")
+
+
+def test_multi_point_launch_with_a_default_exponent_point_against_the_oracle(gpu):
+    """A sweep that contains the reference's own point (n = 2, a0 = 0.009, psi_sat = -0.0047, where the oracle is pinned by
+    G1-G5) next to three others: its members inside the multi-point launch against the oracle, 96 chained rows."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import SweepSimulation, check_sweep_points
+    from hydromodel_amd.synthetic import default_parameters
+    from oracle.oracle import Oracle
+    params = default_parameters()
+    pts = [{"Soil_Properties": {"n": 1.7, "a0": 0.02}}, {"Soil_Properties": {"n": 2.0}},
+           {"Soil_Properties": {"n": 2.6, "a0": 0.004, "psi_sat": -0.5}}, {"Soil_Properties": {"a0": 0.015}}]
+    cols_all = [ColumnTables(mp, WELLS[200]) for mp in check_sweep_points(params, pts)]
+    forcing = ForcingDigest(params, forcing_frame(1), cols_all[0])
+    ic = golden("g1_tables_200.npz")["initial_cond"]
+    M, rows = 16, 96
+    big = SweepSimulation(cols_all, forcing, M, seed=23, psi0=np.tile(ic, (4, 1)))
+    out = big.advance(rows, want_wtd=True, want_psi=True)
+    probe = gpu.EnsembleStepper(cols_all[1], forcing, 1)
+    probe.set_noise_philox(23, 0)
+    o = Oracle(cols_all[1], forcing.surface_evap)
+    n_fresh = int(forcing.refresh[1:1 + rows].sum())
+    equal = 0
+    for k in range(3):
+        gid = 1 * M + k
+        base = probe.philox_normals(gid, 0)
+        fresh = np.stack([probe.philox_normals(gid, q + 1) for q in range(n_fresh)])
+        r = o.run(forcing, ic, base, fresh, 1, 1 + rows, want_psi=True)
+        want = r["psi_rows"][1:1 + rows]
+        e = np.max(np.abs(out["psi"][:, gid, :] - want) / (1 + np.abs(want)), axis=1)
+        assert e[0] < 1e-8 and e.max() < 5e-3, (k, e[0], e.max())
+        equal += int((out["wtd"][:, gid] == r["wtd_est"][1:1 + rows]).sum())
+    assert equal >= 0.98 * 3 * rows
+    probe.close()
+    big.close()
+
+
+def test_point_walk_order_changes_no_result(gpu, monkeypatch):
+    """From the second launch on the chunk ticket walks the points costliest-first; HYDROCOL_POINT_ORDER=fixed keeps
+    point order.  Same states, same moments, same per-point costs."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import SweepSimulation, check_sweep_points
+    from hydromodel_amd.synthetic import default_parameters
+    params = default_parameters()
+    pts = [{"Soil_Properties": {"n": n, "a0": a0}} for n, a0 in ((1.6, 0.004), (2.9, 0.03), (2.0, 0.009), (2.5, 0.02),
+                                                                   (1.8, 0.012))]
+    cols_all = [ColumnTables(mp, WELLS[200]) for mp in check_sweep_points(params, pts)]
+    forcing = ForcingDigest(params, forcing_frame(1), cols_all[0])
+    ic = golden("g1_tables_200.npz")["initial_cond"]
+    res = []
+    for fixed in (False, True):
+        if fixed:
+            monkeypatch.setenv("HYDROCOL_POINT_ORDER", "fixed")
+        sim = SweepSimulation(cols_all, forcing, 40, seed=3, psi0=np.tile(ic, (5, 1)))
+        sim.stepper.set_rows_per_launch(24)
+        sim.advance(96)                                   # four launches: three of them in cost order
+        res.append((sim.stepper.get_state(), sim.moments(), sim.stepper.point_costs()))
+        assert sim.launches == 4
+        sim.close()
+    monkeypatch.delenv("HYDROCOL_POINT_ORDER")
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    cost = res[0][2]
+    print("RHS evaluations per column-step by point:", np.round(cost / (40 * 96.0), 1).tolist())
+    assert cost.min() >= 40 * 96 * 8
+
+
+def test_ensemble_resume_is_bit_exact(gpu, tmp_path):
+    """30 days in one go == 10 days, dump, NEW handle, restore, 20 days: states, moments, damping factors, counters
+    (VERDICT r2 missing 3; the reference's single-column analogue is IC_Filename, simulation.py:358-385).  A lowered
+    iteration budget makes failed attempts -- and with them per-member noise damping -- certain in the first 10 days."""
+    from hydromodel_amd.ensemble import EnsembleSimulation
+    _, cols, forcing = digest(200)
+    ic = golden("g1_tables_200.npz")["initial_cond"]
+    N, budget = 1536, 60
+
+    def start():
+        sim = EnsembleSimulation(cols, forcing, N, seed=41, member_offset=7000, psi0=ic)
+        sim.stepper.set_iteration_budget(budget)
+        return sim
+
+    whole = start()
+    whole.advance(48 * 30)
+    first = start()
+    first.advance(48 * 10)
+    scale_at_dump = first.stepper.noise_scale()
+    assert (scale_at_dump < 1.0).any()                                       # the damping state is not trivial
+    print(f"resume test: {np.unique(scale_at_dump).size} distinct damping factors at the dump, "
+          f"{(scale_at_dump < 1.0).sum()} of {N} members damped")
+    c_first = first.stepper.counters()
+    path = first.dump(tmp_path / "ckpt.h5")
+    first.close()
+    second = EnsembleSimulation.restore(path, cols, forcing)
+    second.stepper.set_iteration_budget(budget)
+    assert second.next_row == 1 + 480 and second.n_members == N and second.member_offset == 7000
+    assert np.array_equal(second.stepper.noise_scale(), scale_at_dump)
+    second.advance(48 * 20)
+    assert np.array_equal(second.stepper.get_state(), whole.stepper.get_state())
+    assert np.array_equal(second.moments(), whole.moments())
+    assert np.array_equal(second.stepper.noise_scale(), whole.stepper.noise_scale())
+    c_whole, c_second = whole.stepper.counters(), second.stepper.counters()
+    for key in ("failed_attempts", "guard_trips", "jac_retry"):
+        assert c_first[key] + c_second[key] == c_whole[key], key
+    assert c_whole["failed_attempts"] > 0
+    # a checkpoint is refused where it does not fit
+    _, cols300, forcing300 = digest(300)
+    with pytest.raises(ValueError, match="does not fit"):
+        EnsembleSimulation.restore(path, cols300, forcing300)
+    from hydromodel_amd._lib import HcError
+    with pytest.raises(HcError):
+        second.stepper.set_noise_scale(np.full(N, 1.5))                      # not a product of 0.8 factors
+    whole.close()
+    second.close()
+
+
+def test_in_library_rccl_allreduce_on_one_gpu(gpu):
+    """hc_allreduce_moments: the path's collective inside the library (RCCL bound with dlopen, no torch).  One GPU is
+    what a round can reach: a one-handle "group" must hand the table back unchanged through ncclAllReduce, and the
+    argument checks must hold (two handles on one device are refused)."""
+    from hydromodel_amd._lib import HcError
+    from hydromodel_amd.stepper import allreduce_handles
+    _, cols, forcing = digest(200)
+    ic = golden("g1_tables_200.npz")["initial_cond"]
+    st = gpu.EnsembleStepper(cols, forcing, 64)
+    st.set_state(ic)
+    st.set_noise_philox(5, 0)
+    st.step_rows(1, 48)
+    before = st.moments()
+    assert before[0, 1:49].tolist() == [64] * 48
+    allreduce_handles([st])
+    assert np.array_equal(st.moments(), before)
+    other = gpu.EnsembleStepper(cols, forcing, 64)
+    with pytest.raises(HcError, match="one handle per device"):
+        allreduce_handles([st, other])
+    other.close()
+    st.close()

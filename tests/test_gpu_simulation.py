@@ -59,7 +59,8 @@ def test_year_long_run_tracks_the_reference(year_run):
     assert diff.max() <= 1
     assert (diff[:1400] == 0).mean() > 0.97
     assert (diff[:2900] == 0).mean() > 0.85
-    assert (diff == 0).mean() > 0.60
+    assert (diff == 0).mean() >= 0.90          # measured 93.3 % (the oracle from the reference's own IC: 97.2 %); see
+    #                                            test_whole_year_reference_oracle_and_gpu_side_by_side for all three
     assert abs(out["abs_error"].mean() - g["abs_error"].mean()) < 2.5      # half a grid cell, year average
     # daily theta profile statistics agree (noise-free diagnostic)
     keep = g["daily_rows"]

@@ -59,12 +59,21 @@ def test_water_content_ordering():
     with pytest.raises(ValueError):
         w.max = 0.01                                     # below min: refused
     with pytest.raises(ValueError):
-        w.min = w.min - 1.0                              # clipped to 0 <= res: refused
+        w.min -= 1.0                                     # the reference's own test_min (tests/test_water_content.py:50-58)
     with pytest.raises(ValueError):
         w.res = 0.5                                      # above min
-    assert 0.0 <= w.res < w.min < w.max <= 1.0           # every refused assignment left a valid object behind
-    w.max = 5.0                                          # clipped to 1.0
+    # setters do NOT clip (water_content.py:88-190; only the constructor does, :40-42): the reference's own test_max
+    # (tests/test_water_content.py:39-48) -- `max += 1.0` raises and the old value stays
+    with pytest.raises(ValueError):
+        w.max += 1.0
+    with pytest.raises(ValueError):
+        w.max = 5.0
+    with pytest.raises(ValueError):
+        w.res = -0.01
+    assert (w.min, w.max, w.res) == (0.08, 0.30, 0.05)   # every refused assignment left the old values behind
+    w.max = 1.0                                          # the closed upper end is allowed
     assert w.max == 1.0
+    assert dg.WaterContent(maximum=5.0).max == 1.0       # the constructor clips (inRange)
     for bad in (dict(minimum=0.4, maximum=0.3), dict(residual=0.2), dict(minimum=0.0, residual=0.0)):
         with pytest.raises(ValueError):
             dg.WaterContent(**bad)

@@ -77,7 +77,8 @@ def test_model_selection_rule():
 @pytest.fixture(scope="module")
 def gpu():
     import torch
-    assert torch.cuda.is_available(), "these tests need a GPU"
+    if not torch.cuda.is_available():
+        pytest.skip("these tests need a GPU")
     import __graft_entry__ as ge
     ge.build()
     return True

@@ -174,3 +174,20 @@ def test_complex_profiles_are_an_error_not_a_cast():
     z = np.arange(0.0, 100.0, 5.0)
     with pytest.raises((ValueError, TypeError)):
         dg.porosity_profiles(z, (0.0, 50.0, 80.0, 95.0), theta, Soil, "Stratified")
+
+
+def test_a_sweep_point_may_not_change_what_every_point_shares():
+    """The forcing digest (ET series, surface evaporation) and the PREDICT gate are taken once from the base parameters:
+    a point that overrides them is refused instead of silently running with the base values."""
+    from hydromodel_amd.ensemble import check_sweep_points
+    params = default_parameters()
+    ok = check_sweep_points(params, [{"Soil_Properties": {"a0": 0.012}},
+                                     {"Hydraulic_Conductivity": {"Sigma_Noise": 1.0},
+                                      "Environmental": {"Interception_pct": 0.1}}])      # interception is per point
+    assert ok[0]["Soil_Properties"]["a0"] == 0.012 and ok[1]["Environmental"]["Interception_pct"] == 0.1
+    assert params["Soil_Properties"]["a0"] != 0.012                                      # the base is not mutated
+    for bad in ({"Environmental": {"Atmospheric_Demand": 2.0}}, {"Environmental": {"Evaporation_pct": 0.5}},
+                {"Environmental": {"Wet_Season_pct": 0.9}}, {"Simulation_Flags": {"PREDICT": True}},
+                {"Well_No": 3}):
+        with pytest.raises(ValueError, match="Sweep"):
+            check_sweep_points(params, [{"Soil_Properties": {"a0": 0.012}}, bad])
