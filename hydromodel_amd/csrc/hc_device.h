@@ -652,6 +652,43 @@ __device__ __forceinline__ int deepest_true(const bool (&pred)[CPL])
     return uniform_i(best);
 }
 
+// region stamps inside rhs_eval (development builds, see HC_STAMP in hc_step.h): 24 cell model, 25 flux / hydraulic
+// lift, 26 evapo-transpiration, 27 lateral flow, 28 top boundary, 29 assembly
+#ifdef HC_PROFILE
+#define HC_RHS_PROF_PARAM , unsigned long long *rprof, unsigned long long &rprof_t, int &rprof_slot
+#define HC_RHS_PROF_ARG , prof_lds, prof_t, prof_slot
+#define HC_RSTAMP(slot)                                                  \
+    {                                                                    \
+        const unsigned long long now_ = clock64();                       \
+        if (lane == 0) {                                                 \
+            rprof[rprof_slot] += (unsigned)(now_ - rprof_t);             \
+            rprof[32 + (slot)] += 1;                                     \
+        }                                                                \
+        rprof_t = now_;                                                  \
+        rprof_slot = (slot);                                             \
+    }
+#define HC_RSUB(slot)                                \
+    {                                                \
+        if (lane == 0) rprof[32 + (slot)] += 1;      \
+    }
+#define HC_RSUB_END()
+#else
+#define HC_RHS_PROF_PARAM
+#define HC_RHS_PROF_ARG
+#ifdef HC_MARKS
+#define HC_RSTAMP(slot) asm volatile("; HCMARK %0" ::"n"(slot))
+#define HC_RSUB(slot) asm volatile("; HCMARK %0" ::"n"(slot))
+#define HC_RSUB_END() asm volatile("; HCMARK -2")
+#else
+#define HC_RSTAMP(slot)
+#define HC_RSUB(slot)
+#define HC_RSUB_END()
+#endif
+#endif
+// Sub-regions (ids 32..63: entries counted, cycles stay with the enclosing region): 33-37 change_D at order 1-5, 41-45
+// accept_update, 49-53 predictor, 56 ET interior call, 57 its water_k > 0 block, 58 the tot_x > 1 renormalisation,
+// 59 ET first-midpoint call, 60 lateral-flow sink, 61 hydraulic lift, 62 FD-Jacobian step sizes, 63 group scatter
+
 // ---------------------------------------------------------------- RHS of the method of lines
 // y[c]   : state at node lane*CPL + c
 // rnd[c] : scaled noise of the cell evaluated in slot c (midpoint lane*CPL+c; the virtual top-node
@@ -663,7 +700,7 @@ __device__ __forceinline__ int deepest_true(const bool (&pred)[CPL])
 template <int CPL, bool SPECIAL, bool PREDICT>
 __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, const double *tab,
                                          int lane, const double (&y)[CPL], const double (&rnd)[CPL],
-                                         double (&f)[CPL], double *aux, double &diag_tr, double &diag_lf)
+                                         double (&f)[CPL], double *aux, double &diag_tr, double &diag_lf HC_RHS_PROF_PARAM)
 {
     constexpr int SLOTS = WAVE * CPL;
     const int D = P.D;
@@ -694,6 +731,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                 dym[c] = (yn - y[c]) * P.inv_dz;
             }
         }
+        HC_RSTAMP(24);
         if (SPECIAL) {
             // batches of HC_MODEL_BATCH cells: enough independent chains to hide the fp64 latency, few
             // enough to keep the working set in VGPRs
@@ -720,6 +758,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                                                                 th + NB * B, Kc + NB * B, Cc + NB * B, kbv + NB * B,
                                                                 pfv + NB * B);
         }
+        HC_RSTAMP(25);
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
             fl[c] = Kc[c] * (dym[c] - 1.0);
@@ -732,6 +771,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     const bool normal_mode = !R.spinup;
     // ---- hydraulic lift (night only), richards_pde.py:234-254
     if (P.flag_hlift && normal_mode && !R.daylight) {
+        HC_RSUB(61);
         const double c_sat = 1800.0 * P.lai;
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
@@ -745,11 +785,13 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         }
     }
     // ---- evapo-transpiration (daylight only), richards_pde.py:258-302 + tree_roots.py:213-291
+    HC_RSTAMP(26);
     if (P.flag_et && normal_mode && R.daylight) {
         // (a) interior call: midpoints 1..n_root_int, normalised together.
         // alpha_02 (tree_roots.py:245-265) is exactly 1 where theta > field capacity and 0 elsewhere:
         // inside (wlt, fc] the reference's (theta - fc)/(fc - wlt) is <= 0 and gets clipped to 0.
         if (P.n_root_int > 0) {
+            HC_RSUB(56);
             bool isr[CPL];
             double pre[CPL], t_wlt[CPL], t_fc[CPL], t_invd1[CPL], t_root[CPL];
             double s_w = 0.0, s_t = 0.0;
@@ -779,6 +821,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             double x_out[CPL];
             double tot_x = 0.0;
             if (water_k > 0.0) {
+                HC_RSUB(57);
                 double total = tot_theta * P.dz;
                 total = total == 0.0 ? 1.0 : total;
                 const double inv_total = fast_rcp(total);
@@ -815,6 +858,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                 for (int c = 0; c < CPL; c++) x_out[c] = 0.0;
             }
             if (tot_x > 1.0) {
+                HC_RSUB(58);
                 const double inv_tx = fast_rcp(tot_x);
                 double s_x = 0.0;
 #pragma unroll
@@ -838,6 +882,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         }
         // (b) first-midpoint call: one cell normalised on its own
         if (P.n_root_first > 0) {
+            HC_RSUB(59);
             // evaluated by every lane on its own slot-0 cell (no divergent branch); only lane 0's result is kept
             const double t0 = th[0], w0 = tab[T_WLT * SLOTS + lane], f0 = tab[T_FC * SLOTS + lane];
             const double water_k = fmax((t0 - w0) * P.dz, 0.0);
@@ -861,6 +906,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     }
     // ---- lateral flow, monitoring mode, richards_pde.py:352-376 (interior slice only; the
     //      single-cell first call can never satisfy wtd_est < wtd_obs)
+    HC_RSTAMP(27);
     if (P.flag_lf) {
         const int k = D - 2;
         bool unsat[CPL];
@@ -904,6 +950,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             if (P.predict_first)   // single-cell call: wtd_est = 0 < low_lim, alpha_lat = alpha_low (1 - 0 ** 1.5)
                 sk[0] = lane == 0 ? fmin(alpha_low * ym[0], sk[0]) : sk[0];
         } else if (wtd_est < wtd_obs) {
+            HC_RSUB(60);
             double s_l = 0.0;
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
@@ -916,6 +963,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         }
     }
     // ---- top boundary, richards_pde.py:414-476 (computed in lane 63's spare slot)
+    HC_RSTAMP(28);
     double pL;
     {
         const double qinf = fmin(2.0 * (P.por_node0 - th_top) * P.dz, kb_top);
@@ -932,6 +980,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     //   dy/dt_i = (f_i - f_{i-1} + h (s_i + s_{i-1})) / (h (c_i + c_{i-1})),   h = dz/2,
     // with (c, s, f)_{-1} = (0, 0, -pL) at the top and (c, s, f)_{D-1} = 0 at the bottom, which is
     // :119 and :155 after cancelling the signs; padding nodes come out as 0/1 = 0.
+    HC_RSTAMP(29);
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const double valid = tab[T_VALID * SLOTS + c * WAVE + lane];    // 1.0 / 0.0; the cell values are finite

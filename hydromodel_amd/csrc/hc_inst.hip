@@ -38,6 +38,11 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
     R.diag = 0;
     double y[CPL], rnd[CPL], f[CPL];
     double dtr = 0.0, dlf = 0.0;
+#ifdef HC_PROFILE
+    unsigned long long prof_dummy[64], prof_t = 0;     // rhs_eval's region stamps go nowhere in the hook
+    unsigned long long *prof_lds = prof_dummy;
+    int prof_slot = 0;
+#endif
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const int i = lane * CPL + c;
@@ -63,12 +68,12 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
 #ifdef HC_PROFILE
     // diagnostic build: repeat the evaluation (loop-carried through y) to time the RHS alone
     for (long long rep = 1; rep < A.n_rows; rep++) {
-        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, nullptr, dtr, dlf);
+        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, nullptr, dtr, dlf HC_RHS_PROF_ARG);
 #pragma unroll
         for (int c = 0; c < CPL; c++) y[c] = fma(f[c], 1e-300, y[c]);
     }
 #endif
-    rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr, dtr, dlf);
+    rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr, dtr, dlf HC_RHS_PROF_ARG);
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const int i = lane * CPL + c;

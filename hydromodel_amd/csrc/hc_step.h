@@ -29,6 +29,36 @@ constexpr double NUM_JAC_DIFF_SMALL = 1.8189894035458565e-12;
 constexpr double NUM_JAC_DIFF_BIG = 0.0001220703125;
 constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 
+// Region accounting of the development builds (tools/isa_account.py, tools/prof_phases.py):
+//   -DHC_PROFILE: cycles spent in and entries into each region, summed over waves (clock64 stamps; costs ~3 %)
+//   -DHC_MARKS  : the same region ids as assembler comments ("; HCMARK n") -- zero instructions -- so that the static
+//                 instruction mix of each region can be read off the .s file of the production kernel
+#ifdef HC_PROFILE
+#define HC_STAMP(slot)                                                   \
+    {                                                                    \
+        const unsigned long long now_ = clock64();                       \
+        if (lane == 0) {                                                 \
+            prof_lds[prof_slot] += (unsigned)(now_ - prof_t);            \
+            prof_lds[32 + (slot)] += 1;                                  \
+        }                                                                \
+        prof_t = now_;                                                   \
+        prof_slot = (slot);                                              \
+    }
+#define HC_SUB(slot)                                                                              \
+    {                                                                                             \
+        if (lane == 0) reinterpret_cast<unsigned long long *>(ru + 160)[32 + (slot)] += 1;        \
+    }
+#define HC_SUB_END()
+#elif defined(HC_MARKS)
+#define HC_STAMP(slot) asm volatile("; HCMARK %0" ::"n"(slot))
+#define HC_SUB(slot) asm volatile("; HCMARK %0" ::"n"(slot))
+#define HC_SUB_END() asm volatile("; HCMARK -2")
+#else
+#define HC_STAMP(slot)
+#define HC_SUB(slot)
+#define HC_SUB_END()
+#endif
+
 // Per-wave vectors (each 64*CPL doubles): the accepted state, the base f of a Jacobian, the FD step factors, the BDF
 // difference rows D[0..7] and the row's noise vector.
 // V_Y0, the state a row starts from, is only needed again when an attempt fails: deep columns (CPL > 5) keep it in the
@@ -36,7 +66,7 @@ constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 // as well was measured at D = 401 / 461 / 581: 7 % slower -- the compiler's own scratch placement does better.)
 enum { V_Y = 0, V_FP, V_FAC, V_D0, V_NZ = V_D0 + MAX_ORDER + 3, NVEC = V_NZ + 1, V_Y0 = NVEC };
 #ifdef HC_PROFILE
-constexpr int WAVE_SCRATCH = 192;
+constexpr int WAVE_SCRATCH = 256;   // + per wave: 32 cycle sums, 32 entry counts, 32 sub-region entry counts
 #else
 constexpr int WAVE_SCRATCH = 160;
 #endif
@@ -309,12 +339,13 @@ __device__ __forceinline__ void change_D(const WaveVecs<CPL> &W, double *ru, int
     }
     __builtin_amdgcn_wave_barrier();
     switch (order) {
-        case 1: apply_RU<CPL, 1>(W, ru, lane); break;
-        case 2: apply_RU<CPL, 2>(W, ru, lane); break;
-        case 3: apply_RU<CPL, 3>(W, ru, lane); break;
-        case 4: apply_RU<CPL, 4>(W, ru, lane); break;
-        default: apply_RU<CPL, 5>(W, ru, lane); break;
+        case 1: HC_SUB(33); apply_RU<CPL, 1>(W, ru, lane); break;
+        case 2: HC_SUB(34); apply_RU<CPL, 2>(W, ru, lane); break;
+        case 3: HC_SUB(35); apply_RU<CPL, 3>(W, ru, lane); break;
+        case 4: HC_SUB(36); apply_RU<CPL, 4>(W, ru, lane); break;
+        default: HC_SUB(37); apply_RU<CPL, 5>(W, ru, lane); break;
     }
+    HC_SUB_END();
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -487,17 +518,6 @@ __device__ __forceinline__ void col_stats(bool hasU, bool hasD, double fnU, doub
     sc = fmax(fabs(sf), fabs(sn));
 }
 
-#ifdef HC_PROFILE
-#define HC_STAMP(slot)                                                   \
-    {                                                                    \
-        const unsigned long long now_ = clock64();                       \
-        if (lane == 0) prof_lds[prof_slot] += (unsigned)(now_ - prof_t); \
-        prof_t = now_;                                                   \
-        prof_slot = (slot);                                              \
-    }
-#else
-#define HC_STAMP(slot)
-#endif
 
 enum Phase {
     PH_F0 = 0, PH_F1, PH_JAC, PH_JAC_REDO, PH_NEWTON,
@@ -544,7 +564,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     int *flags_lds = reinterpret_cast<int *>(ru + 124);   // per-lane column flags of the FD-Jacobian retry pass
 #ifdef HC_PROFILE
     unsigned long long *prof_lds = reinterpret_cast<unsigned long long *>(ru + 160);
-    if (lane < 32) prof_lds[lane] = 0;
+    prof_lds[lane] = 0;          // [0..31] cycles per region, [32..63] entries per region, [64..95] sub-region entries
+    if (lane < 32) prof_lds[64 + lane] = 0;
     int prof_slot = 31;
 #endif
     WaveVecs<CPL> W;
@@ -779,14 +800,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                 unsigned long long prof_t = clock64();
 #endif
                 for (;;) {
-#ifdef HC_PROFILE
-                    {   // diagnostic build only: cycles per phase (the slot after the RHS site is phase + 16)
-                        const unsigned long long now = clock64();
-                        if (lane == 0) prof_lds[prof_slot] += (unsigned)(now - prof_t);
-                        prof_t = now;
-                        prof_slot = phase;
-                    }
-#endif
+                    HC_STAMP(31);   // loop top: budget check, dispatch to the RHS site
 #ifdef HC_PROFILE
                     {   // diagnostic build: (phase, t, h_abs, order, n_equal + 100 * current_jac + 1000 * have_lu, last norm)
                         const IoArgs iot = load_const(A.io);
@@ -814,12 +828,9 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         phase = C_FAIL;
                     }
                     if (phase < C_SUCCESS) {
-                        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf);
-#ifdef HC_PROFILE
-                        const unsigned long long now = clock64();
-                        if (lane == 0) prof_lds[16] += (unsigned)(now - prof_t);
-                        prof_t = now;
-#endif
+                        HC_STAMP(16);   // RHS prologue (midpoints); rhs_eval stamps its own regions 24..29
+                        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf HC_RHS_PROF_ARG);
+                        HC_STAMP(17);   // after the RHS: dispatch to the phase block
                     }
                     // Phases run in topological order inside ONE loop iteration: a block that hands over to a
                     // later block falls through to it; only blocks that need a fresh RHS value end the iteration.
@@ -1016,6 +1027,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         HC_STAMP(PH_JAC);
                         HC_GROUPS();
                         if (g < 0) {
+                            HC_SUB(62);
                             // common.num_jac: step h per column from factor, f sign and |y|
 #pragma unroll
                             for (int c = 0; c < CPL; c++) {
@@ -1033,6 +1045,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             }
                             g = 0;
                         } else {
+                            HC_SUB(63);
                             // f holds fun(y + h * [group == g]); scatter into the three per-row slots
                             const double r0v = readlane_d(f[0], 0);
                             if (lane == 0) row0[g] = r0v;
@@ -1044,6 +1057,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             }
                             g++;
                         }
+                        HC_SUB_END();
                         if (g < A.n_groups) {
 #pragma unroll
                             for (int c = 0; c < CPL; c++) ycur[c] = yp[c] + ((gs[c] == g) ? hj[c] : 0.0);
@@ -1171,12 +1185,13 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #pragma unroll
                         for (int c = 0; c < CPL; c++) W.template st<V_Y>(c * WAVE + lane, ycur[c]);   // sol.y[:, -1] so far
                         switch (order) {
-                            case 1: accept_update<CPL, 1>(W, dd, lane, d_ord, d_ord2); break;
-                            case 2: accept_update<CPL, 2>(W, dd, lane, d_ord, d_ord2); break;
-                            case 3: accept_update<CPL, 3>(W, dd, lane, d_ord, d_ord2); break;
-                            case 4: accept_update<CPL, 4>(W, dd, lane, d_ord, d_ord2); break;
-                            default: accept_update<CPL, 5>(W, dd, lane, d_ord, d_ord2); break;
+                            case 1: HC_SUB(41); accept_update<CPL, 1>(W, dd, lane, d_ord, d_ord2); break;
+                            case 2: HC_SUB(42); accept_update<CPL, 2>(W, dd, lane, d_ord, d_ord2); break;
+                            case 3: HC_SUB(43); accept_update<CPL, 3>(W, dd, lane, d_ord, d_ord2); break;
+                            case 4: HC_SUB(44); accept_update<CPL, 4>(W, dd, lane, d_ord, d_ord2); break;
+                            default: HC_SUB(45); accept_update<CPL, 5>(W, dd, lane, d_ord, d_ord2); break;
                         }
+                        HC_SUB_END();
                         if (t == tf) {
                             phase = C_SUCCESS;
                         } else if (n_equal < order + 1) {
@@ -1246,12 +1261,13 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             h_abs = fabs(h);
                             const double inv_alpha = 1.0 / alpha_k(order);
                             switch (order) {
-                                case 1: predict<CPL, 1>(W, lane, inv_alpha, yp, psiv); break;
-                                case 2: predict<CPL, 2>(W, lane, inv_alpha, yp, psiv); break;
-                                case 3: predict<CPL, 3>(W, lane, inv_alpha, yp, psiv); break;
-                                case 4: predict<CPL, 4>(W, lane, inv_alpha, yp, psiv); break;
-                                default: predict<CPL, 5>(W, lane, inv_alpha, yp, psiv); break;
+                                case 1: HC_SUB(49); predict<CPL, 1>(W, lane, inv_alpha, yp, psiv); break;
+                                case 2: HC_SUB(50); predict<CPL, 2>(W, lane, inv_alpha, yp, psiv); break;
+                                case 3: HC_SUB(51); predict<CPL, 3>(W, lane, inv_alpha, yp, psiv); break;
+                                case 4: HC_SUB(52); predict<CPL, 4>(W, lane, inv_alpha, yp, psiv); break;
+                                default: HC_SUB(53); predict<CPL, 5>(W, lane, inv_alpha, yp, psiv); break;
                             }
+                            HC_SUB_END();
 #pragma unroll
                             for (int c = 0; c < CPL; c++) scl[c] = fast_div(1.0, ATOL + RTOL * fabs(yp[c]));
                             cc = h / alpha_k(order);
@@ -1373,7 +1389,10 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #ifdef HC_PROFILE
         __builtin_amdgcn_wave_barrier();
         if (lane < 32) atomicAdd(&io.counters[8 + lane], prof_lds[lane]);
-        if (lane < 32) prof_lds[lane] = 0;
+        if (lane >= 32) atomicAdd(&io.counters[32 + lane], prof_lds[lane]);     // entries: counters[64..95]
+        if (lane < 32) atomicAdd(&io.counters[96 + lane], prof_lds[64 + lane]);  // sub-region entries: counters[96..127]
+        prof_lds[lane] = 0;
+        if (lane < 32) prof_lds[64 + lane] = 0;
 #endif
     }
     }   // next member

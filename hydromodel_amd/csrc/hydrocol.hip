@@ -498,8 +498,8 @@ int hc_create(int device_ordinal, hc_handle **out)
         HIP_TRY(hipStreamCreate(&h->stream));
         HIP_TRY(hipEventCreate(&h->ev0));
         HIP_TRY(hipEventCreate(&h->ev1));
-        if (h->counters.ensure(64) != HC_OK) return HC_ERR_DEVICE;
-        HIP_TRY(hipMemset(h->counters.p, 0, 64 * sizeof(unsigned long long)));
+        if (h->counters.ensure(128) != HC_OK) return HC_ERR_DEVICE;
+        HIP_TRY(hipMemset(h->counters.p, 0, 128 * sizeof(unsigned long long)));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
         h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1003,6 +1003,20 @@ extern "C" int hc_debug_profile(hc_handle *h, uint64_t *out32)
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(out32, h->counters.p + 8, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+extern "C" int hc_debug_profile_counts(hc_handle *h, uint64_t *out32)      // entries into each region
+{
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out32, h->counters.p + 64, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HC_OK;
+}
+extern "C" int hc_debug_profile_subcounts(hc_handle *h, uint64_t *out32)   // entries into sub-regions 32..63
+{
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out32, h->counters.p + 96, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return HC_OK;
 }
 #endif

@@ -25,13 +25,21 @@ it = np.asarray(sim.spinup_iters)
 print(f"{len(pts)} points x {M} members, D={D}: spin-ups {t_spin:.1f} s, iterations min/median/max {it.min()}/{int(np.median(np.abs(it)))}/{it.max()}, "
       f"capped {(it < 0).sum()}", flush=True)
 done = 0
+cost_prev, ms_prev = sim.stepper.point_costs().astype(float), 0.0
 while done < days:
     n = min(5, days - done)
     sim.advance(48 * n)
     done += n
     y = sim.stepper.get_state()
     assert np.isfinite(y).all(), f"non-finite state after day {done}"
-    print(f"day {done}: psi range [{y.min():.1f}, {y.max():.1f}], counters {sim.stepper.counters()}", flush=True)
+    cost = sim.stepper.point_costs().astype(float)
+    d_cost, d_ms = cost - cost_prev, sim.kernel_ms - ms_prev
+    cost_prev, ms_prev = cost, sim.kernel_ms
+    # RHS evaluations per second of kernel time: constant while the launch keeps every wavefront busy
+    print(f"day {done}: psi range [{y.min():.1f}, {y.max():.1f}], counters {sim.stepper.counters()}; these {n} days: "
+          f"{len(pts) * M * n / (d_ms * 1e-3):.0f} column-days/s, {d_cost.sum() / (d_ms * 1e-3) / 1e9:.2f} G RHS evaluations/s, "
+          f"costliest point {d_cost.max() / (M * n * 48):.1f} evaluations per column-step (median {np.median(d_cost) / (M * n * 48):.1f})",
+          flush=True)
 m = sim.moments()
 mean_idx = m[:, 1, 1:48 * days + 1] / m[:, 0, 1:48 * days + 1]
 print(json.dumps({"points": len(pts), "members": M, "days": days, "column_days_per_s": len(pts) * M * days / (sim.kernel_ms * 1e-3),
