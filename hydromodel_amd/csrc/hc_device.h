@@ -257,6 +257,133 @@ __device__ __forceinline__ double rsqrt_ge1(double x)
     return fma(y * e, fma(e, 0.375, 0.5), y);
 }
 
+// ---------------------------------------------------------------- one or two wavefronts per member
+// Columns deeper than 512 nodes are SPLIT over two cooperating wavefronts of one workgroup (waves 2p and 2p + 1): half h
+// owns the nodes [h * 64 CPL, (h + 1) * 64 CPL), again CPL consecutive nodes per lane.  One wave cannot hold the working
+// set of a 640-node column (hipcc 7.2: 1.5 KB of scratch per lane at 10 cells per lane); two waves hold it in two
+// register files with no scratch at all.  What crosses the cut -- the stencil's edge values, every reduction, the
+// coupling of the two tridiagonal blocks -- goes through a mailbox in LDS: double-buffered payload, one sequence counter
+// per half (release store / acquire load at workgroup scope), no s_barrier (the other pair of the workgroup runs another
+// member with its own control flow).  Both halves execute the same sequence of exchanges: every branch that contains
+// one is decided by values both halves hold identically.
+struct PairBox {
+    double data[2][2][8];      // [exchange parity][half][value]
+    unsigned seq[2];           // exchanges posted by each half
+    unsigned pad_[2];
+};
+
+template <int HALVES>
+struct Comm;
+
+// one wave per member: everything stays inside the wave, the compiler sees exactly the code it saw before
+template <>
+struct Comm<1> {
+    static constexpr int H = 1;
+    int half;                  // always 0
+    static constexpr bool dead = false;
+    __device__ __forceinline__ double sum(double v) const { return wave_sum(v); }
+    __device__ __forceinline__ void sum2(double &a, double &b) const { wave_sum2(a, b); }
+    __device__ __forceinline__ double up1(double v, int lane, double fill) { return shfl_up1(v, lane, fill); }
+    __device__ __forceinline__ double down1(double v, int lane, double fill) { return shfl_down1(v, lane, fill); }
+    __device__ __forceinline__ double first_row(double v) { return readlane_d(v, 0); }
+    __device__ __forceinline__ bool any(bool p) { return __any(p); }
+    __device__ __forceinline__ int or_bits(int m) { return m; }
+    __device__ __forceinline__ int max_int(int v) { return v; }
+};
+
+template <>
+struct Comm<2> {
+    static constexpr int H = 2;
+    int half;                  // 0: upper half of the column (nodes from 0), 1: lower half
+    int lane;
+    unsigned k;                // exchanges done so far (identical in both halves)
+    PairBox *box;
+    bool dead;                 // an exchange timed out (a bug, never the data): stop waiting, let the member run out
+    unsigned long long *fault; // device counter of such events
+    static constexpr int SPIN_LIMIT = 1 << 22;
+
+    // Every lane of both waves gets the partner's N values.  `mine` are wave-uniform.
+    template <int N>
+    __device__ __forceinline__ void xchg(const double (&mine)[N], double (&theirs)[N])
+    {
+        static_assert(N <= 8, "mailbox holds eight values per half");
+        const unsigned p = k & 1u;
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < N; j++) box->data[p][half][j] = mine[j];
+            __hip_atomic_store(&box->seq[half], k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        int spins = 0;
+        while (!dead && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&box->seq[half ^ 1], __ATOMIC_ACQUIRE,
+                                                                              __HIP_MEMORY_SCOPE_WORKGROUP)) < (int)(k + 1u)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) {          // every wave must reach an exit
+                dead = true;
+                if (lane == 0) atomicAdd(fault, 1ull);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; j++) theirs[j] = uniform_d(box->data[p][half ^ 1][j]);
+        k++;
+    }
+    // upper half's value first: both halves form the same sum, bit for bit
+    __device__ __forceinline__ double sum(double v)
+    {
+        const double mine[1] = {wave_sum(v)};
+        double theirs[1];
+        xchg(mine, theirs);
+        return half == 0 ? mine[0] + theirs[0] : theirs[0] + mine[0];
+    }
+    __device__ __forceinline__ void sum2(double &a, double &b)
+    {
+        wave_sum2(a, b);
+        const double mine[2] = {a, b};
+        double theirs[2];
+        xchg(mine, theirs);
+        a = half == 0 ? mine[0] + theirs[0] : theirs[0] + mine[0];
+        b = half == 0 ? mine[1] + theirs[1] : theirs[1] + mine[1];
+    }
+    // value of the previous / next node's lane across the cut: the lower half's lane 0 takes the upper half's lane 63
+    // and the other way round; the column's outer ends take `fill`
+    __device__ __forceinline__ double up1(double v, int lane_, double fill)
+    {
+        const double mine[1] = {readlane_d(v, WAVE - 1)};
+        double theirs[1];
+        xchg(mine, theirs);
+        return shfl_up1(v, lane_, half == 0 ? fill : theirs[0]);
+    }
+    __device__ __forceinline__ double down1(double v, int lane_, double fill)
+    {
+        const double mine[1] = {readlane_d(v, 0)};
+        double theirs[1];
+        xchg(mine, theirs);
+        return shfl_down1(v, lane_, half == 0 ? theirs[0] : fill);
+    }
+    __device__ __forceinline__ double first_row(double v)      // node 0's value, in both halves
+    {
+        const double mine[1] = {readlane_d(v, 0)};
+        double theirs[1];
+        xchg(mine, theirs);
+        return half == 0 ? mine[0] : theirs[0];
+    }
+    __device__ __forceinline__ int or_bits(int m)              // m wave-uniform
+    {
+        const double mine[1] = {(double)m};
+        double theirs[1];
+        xchg(mine, theirs);
+        return m | (int)theirs[0];
+    }
+    __device__ __forceinline__ bool any(bool p) { return or_bits(__any(p) ? 1 : 0) != 0; }
+    __device__ __forceinline__ int max_int(int v)              // v wave-uniform
+    {
+        const double mine[1] = {(double)v};
+        double theirs[1];
+        xchg(mine, theirs);
+        const int o = (int)theirs[0];
+        return v > o ? v : o;
+    }
+};
+
 // ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4])
@@ -697,12 +824,34 @@ __device__ __forceinline__ int deepest_true(const bool (&pred)[CPL])
 // aux    : optional global pointer [3*(D-1)+1] receiving c | s | f at the midpoints and pL
 // PREDICT: the repaired predictive lateral flow is compiled in (a template parameter, not a run-time flag: the
 // branch costs 1.4 % of the monitoring-mode kernel through register allocation alone when it is merely present)
-template <int CPL, bool SPECIAL, bool PREDICT>
+// top boundary, richards_pde.py:414-476: pL from the plugin's values at the top node
+__device__ __forceinline__ double top_flux(const ColumnDev &P, const RowDev &R, double y_top, double kb_top,
+                                           double th_top, double pf_top)
+{
+    const double qinf = fmin(2.0 * (P.por_node0 - th_top) * P.dz, kb_top);
+    const double net = (1.0 - P.interception) * fabs(R.precip);
+    double p = (y_top < P.psi_sat) ? fmin(net, qinf) : 0.0;
+    if (!R.spinup) {
+        const double q_min = P.theta_res + P.evap_delta_min * pf_top;
+        const bool allow = (th_top > P.theta_res) && (q_min > P.theta_res);
+        p = (allow && R.daylight) ? p - P.surface_evap : p;
+    }
+    return p;
+}
+
+// `tab` points at this wave's first table slot (the lower half of a split column starts 64 CPL slots in); table rows are
+// 64 CPL x CommT::H slots apart.  With CommT = Comm<2> the wave holds one half of the column (see Comm above): the cut
+// costs two mailbox exchanges per evaluation -- the edge states at the start, and in the middle the water-table
+// candidates, the top flux (evaluated by the lower half, whose last slot is free) and the upper half's last cell.
+template <int CPL, bool SPECIAL, bool PREDICT, class CommT>
 __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, const double *tab,
                                          int lane, const double (&y)[CPL], const double (&rnd)[CPL],
-                                         double (&f)[CPL], double *aux, double &diag_tr, double &diag_lf HC_RHS_PROF_PARAM)
+                                         double (&f)[CPL], double *aux, double &diag_tr, double &diag_lf, CommT &comm HC_RHS_PROF_PARAM)
 {
-    constexpr int SLOTS = WAVE * CPL;
+    constexpr int H = CommT::H;
+    constexpr int SLOTS = WAVE * CPL * H;                      // table row stride
+    const int hb = H == 2 ? comm.half * (WAVE * CPL) : 0;      // index of this wave's first node
+    const bool last_half = H == 1 || comm.half == H - 1;
     const int D = P.D;
     const double half = 0.5 * P.dz;
     if (R.diag) {
@@ -710,8 +859,15 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         diag_lf = 0.0;
     }
     double ym[CPL], dym[CPL], th[CPL], Kc[CPL], Cc[CPL], fl[CPL], sk[CPL];
-    const double y_top = readlane_d(y[0], 0);
-    const double y_nf = shfl_down1(y[0], lane, 0.0);
+    double y_top = readlane_d(y[0], 0), y_edge = 0.0;          // node 0; the first node below this wave's last one
+    if constexpr (H == 2) {
+        const double mine[1] = {y_top};
+        double theirs[1];
+        comm.xchg(mine, theirs);
+        y_edge = comm.half == 0 ? theirs[0] : 0.0;
+        y_top = comm.half == 0 ? y_top : theirs[0];
+    }
+    const double y_nf = shfl_down1(y[0], lane, y_edge);
     double kb_top = 0.0, th_top = 0.0, pf_top = 0.0;
     {
         double kbv[CPL], pfv[CPL];
@@ -722,7 +878,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             // top-node cell (last slot of lane 63) needs its own argument.
             const double yn = (c + 1 < CPL) ? y[c + 1 < CPL ? c + 1 : c] : y_nf;
             double psi = 0.5 * (y[c] + yn);
-            if (c == CPL - 1) psi = (lane == WAVE - 1) ? y_top : psi;
+            if (c == CPL - 1) psi = (lane == WAVE - 1 && last_half) ? y_top : psi;
             ym[c] = psi;
             {
                 // the gradient is a rounded value of its own, as in the reference (richards_pde.py:566): it must not
@@ -775,7 +931,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         const double c_sat = 1800.0 * P.lai;
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-            const int i = lane * CPL + c;
+            const int i = hb + lane * CPL + c;
             const bool isr = (i == 0) ? (P.n_root_first > 0) : (i <= P.n_root_int);
             const double root = tab[T_ROOT * SLOTS + c * WAVE + lane];
             const double t1 = 1.0 - P.ipsi50 * ym[c];
@@ -786,7 +942,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     }
     // ---- evapo-transpiration (daylight only), richards_pde.py:258-302 + tree_roots.py:213-291
     HC_RSTAMP(26);
-    if (P.flag_et && normal_mode && R.daylight) {
+    if (P.flag_et && normal_mode && R.daylight && (H == 1 || comm.half == 0)) {   // the root zone lies in the upper half
         // (a) interior call: midpoints 1..n_root_int, normalised together.
         // alpha_02 (tree_roots.py:245-265) is exactly 1 where theta > field capacity and 0 elsewhere:
         // inside (wlt, fc] the reference's (theta - fc)/(fc - wlt) is <= 0 and gets clipped to 0.
@@ -907,15 +1063,47 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     // ---- lateral flow, monitoring mode, richards_pde.py:352-376 (interior slice only; the
     //      single-cell first call can never satisfy wtd_est < wtd_obs)
     HC_RSTAMP(27);
+    // split column: the top flux is the lower half's to compute (its last slot holds the top-node cell) and the
+    // upper half's to use; the upper half's last cell is the lower half's upper neighbour in the assembly
+    double pL_pair = 0.0, edge_C = 0.0, edge_f = 0.0, edge_s = 0.0, edge_ym = 0.0;
+    int jstar_other = -1;
+    if constexpr (H == 2) {
+        const double pl = readlane_d(top_flux(P, R, y_top, kb_top, th_top, pf_top), WAVE - 1);
+        bool unsat0[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int i = hb + lane * CPL + c;
+            unsat0[c] = P.flag_lf && (i >= 1) && (i <= D - 2) && !(ym[c] >= P.psi_sat);
+        }
+        const int j0 = deepest_true<CPL>(unsat0);
+        const double mine[5] = {(double)(j0 < 0 ? -1 : hb + j0), comm.half == 0 ? readlane_d(Cc[CPL - 1], WAVE - 1) : pl,
+                                readlane_d(fl[CPL - 1], WAVE - 1), readlane_d(sk[CPL - 1], WAVE - 1),
+                                readlane_d(ym[CPL - 1], WAVE - 1)};
+        double theirs[5];
+        comm.xchg(mine, theirs);
+        jstar_other = (int)theirs[0];
+        if (comm.half == 0) {
+            pL_pair = theirs[1];
+        } else {
+            edge_C = theirs[1];
+            edge_f = theirs[2];
+            edge_s = theirs[3];
+            edge_ym = theirs[4];
+        }
+    }
     if (P.flag_lf) {
         const int k = D - 2;
         bool unsat[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-            const int i = lane * CPL + c;
+            const int i = hb + lane * CPL + c;
             unsat[c] = (i >= 1) && (i <= D - 2) && !(ym[c] >= P.psi_sat);
         }
-        const int jstar = deepest_true<CPL>(unsat);          // midpoint index, local position p = j-1
+        int jstar = deepest_true<CPL>(unsat);                // midpoint index, local position p = j-1
+        if constexpr (H == 2) {
+            jstar = jstar < 0 ? -1 : hb + jstar;
+            jstar = jstar > jstar_other ? jstar : jstar_other;
+        }
         int wtd_est = jstar < 0 ? 0 : jstar;                  // p* + 1
         wtd_est = wtd_est < k - 1 ? wtd_est : k - 1;
         const int wtd_obs = R.wtd_obs < k - 1 ? R.wtd_obs : k - 1;
@@ -940,32 +1128,36 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                 double s_l = 0.0;
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
-                    const int p = lane * CPL + c - 1;
+                    const int p = hb + lane * CPL + c - 1;
                     const bool in = p == wtd_est;
                     sk[c] = in ? fmin(alpha_lat * ym[c], sk[c]) : sk[c];
                     s_l += in ? fabs(sk[c]) : 0.0;
                 }
-                if (R.diag) diag_lf = wave_sum(s_l) * P.dz;
+                if (H == 2 && hb - 2 == wtd_est) edge_s = fmin(alpha_lat * edge_ym, edge_s);   // the upper half's last cell
+                if (R.diag) diag_lf = comm.sum(s_l) * P.dz;
             }
-            if (P.predict_first)   // single-cell call: wtd_est = 0 < low_lim, alpha_lat = alpha_low (1 - 0 ** 1.5)
+            if (P.predict_first && (H == 1 || comm.half == 0))   // single-cell call: wtd_est = 0 < low_lim, alpha_lat = alpha_low (1 - 0 ** 1.5)
                 sk[0] = lane == 0 ? fmin(alpha_low * ym[0], sk[0]) : sk[0];
         } else if (wtd_est < wtd_obs) {
             HC_RSUB(60);
             double s_l = 0.0;
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
-                const int p = lane * CPL + c - 1;
+                const int p = hb + lane * CPL + c - 1;
                 const bool in = (p >= wtd_est) && (p < wtd_obs);
                 sk[c] = in ? fmin(-2.5e-4 * ym[c], sk[c]) : sk[c];
                 s_l += in ? fabs(sk[c]) : 0.0;
             }
-            if (R.diag) diag_lf = wave_sum(s_l) * P.dz;   // richards_pde.py:374,388
+            if (H == 2 && hb - 2 >= wtd_est && hb - 2 < wtd_obs) edge_s = fmin(-2.5e-4 * edge_ym, edge_s);
+            if (R.diag) diag_lf = comm.sum(s_l) * P.dz;   // richards_pde.py:374,388
         }
     }
     // ---- top boundary, richards_pde.py:414-476 (computed in lane 63's spare slot)
     HC_RSTAMP(28);
     double pL;
-    {
+    if constexpr (H == 2) {
+        pL = pL_pair;                                           // (only the upper half uses it)
+    } else {
         const double qinf = fmin(2.0 * (P.por_node0 - th_top) * P.dz, kb_top);
         const double net = (1.0 - P.interception) * fabs(R.precip);
         double p = (y_top < P.psi_sat) ? fmin(net, qinf) : 0.0;
@@ -987,12 +1179,13 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
         Cc[c] *= valid;
         fl[c] *= valid;
     }
-    const double cP0 = shfl_up1(Cc[CPL - 1], lane, 0.0);
-    const double sP0 = shfl_up1(sk[CPL - 1], lane, 0.0);
-    const double fP0 = shfl_up1(fl[CPL - 1], lane, -pL);
+    const bool upper = H == 1 || comm.half == 0;              // this wave starts at the column's top
+    const double cP0 = shfl_up1(Cc[CPL - 1], lane, upper ? 0.0 : edge_C);
+    const double sP0 = shfl_up1(sk[CPL - 1], lane, upper ? 0.0 : edge_s);
+    const double fP0 = shfl_up1(fl[CPL - 1], lane, upper ? -pL : edge_f);
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
-        const int i = lane * CPL + c;
+        const int i = hb + lane * CPL + c;
         const double cP = c == 0 ? cP0 : Cc[c > 0 ? c - 1 : 0];
         const double sP = c == 0 ? sP0 : sk[c > 0 ? c - 1 : 0];
         const double fP = c == 0 ? fP0 : fl[c > 0 ? c - 1 : 0];

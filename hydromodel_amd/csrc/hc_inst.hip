@@ -4,10 +4,35 @@
 
 #include "hc_launch.h"
 
-#ifndef HC_INST_CPL
-#error "compile with -DHC_INST_CPL=<cells per lane>"
+#if !defined(HC_INST_CPL) && !defined(HC_INST_PAIR)
+#error "compile with -DHC_INST_CPL=<cells per lane> or -DHC_INST_PAIR"
 #endif
 
+#ifdef HC_INST_PAIR
+// ---- the split-column step kernel (two waves per member): its own translation unit
+namespace hc {
+namespace {
+template <bool SPECIAL, bool PREDICT>
+hipError_t step_pair_one(const LaunchCfg &cfg, const StepArgs &A)
+{
+    constexpr int WPB = wpb_of(PAIR_CPL);
+    auto kern = step_kernel<PAIR_CPL, SPECIAL, WPB, PREDICT, 2>;
+    const size_t lds = step_lds_bytes(PAIR_CPL, WPB, 2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(WPB * WAVE), lds, cfg.stream, A);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_step_pair(const LaunchCfg &cfg, const StepArgs &A)
+{
+    if (cfg.special) return cfg.predict ? step_pair_one<true, true>(cfg, A) : step_pair_one<true, false>(cfg, A);
+    return cfg.predict ? step_pair_one<false, true>(cfg, A) : step_pair_one<false, false>(cfg, A);
+}
+}  // namespace hc
+#else
 namespace hc {
 
 // RHS hook: one wave per member, same device path as the stepper
@@ -38,6 +63,8 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
     R.diag = 0;
     double y[CPL], rnd[CPL], f[CPL];
     double dtr = 0.0, dlf = 0.0;
+    Comm<1> comm;
+    comm.half = 0;
 #ifdef HC_PROFILE
     unsigned long long prof_dummy[64], prof_t = 0;     // rhs_eval's region stamps go nowhere in the hook
     unsigned long long *prof_lds = prof_dummy;
@@ -68,12 +95,12 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
 #ifdef HC_PROFILE
     // diagnostic build: repeat the evaluation (loop-carried through y) to time the RHS alone
     for (long long rep = 1; rep < A.n_rows; rep++) {
-        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, nullptr, dtr, dlf HC_RHS_PROF_ARG);
+        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, nullptr, dtr, dlf, comm HC_RHS_PROF_ARG);
 #pragma unroll
         for (int c = 0; c < CPL; c++) y[c] = fma(f[c], 1e-300, y[c]);
     }
 #endif
-    rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr, dtr, dlf HC_RHS_PROF_ARG);
+    rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, y, rnd, f, aux ? aux + member * (3 * (D - 1) + 1) : nullptr, dtr, dlf, comm HC_RHS_PROF_ARG);
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
         const int i = lane * CPL + c;
@@ -137,3 +164,4 @@ hipError_t launch_rhs_cpl<HC_INST_CPL>(const LaunchCfg &cfg, const StepArgs &A, 
 }
 
 }  // namespace hc
+#endif  // HC_INST_PAIR

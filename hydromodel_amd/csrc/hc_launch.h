@@ -21,10 +21,12 @@ struct LaunchCfg {
 // four waves per workgroup (one per SIMD) at every depth: what does not fit in LDS lives in StepArgs::wave_spill
 constexpr int wpb_of(int) { return WAVES_PER_BLOCK; }
 
-inline size_t step_lds_bytes(int cpl, int wpb)
+inline size_t step_lds_bytes(int cpl, int wpb, int halves = 1)
 {
     const size_t slots = (size_t)WAVE * cpl;
-    return NTAB * slots * 8 + 4 * slots * 1 + (size_t)wpb * ((size_t)lds_vectors(cpl) * slots + WAVE_SCRATCH) * 8;
+    return (NTAB * slots * 8 + 4 * slots * 1) * halves +
+           (size_t)wpb * ((size_t)lds_vectors(cpl, halves) * slots + WAVE_SCRATCH) * 8 +
+           (halves == 2 ? (size_t)(wpb / 2) * sizeof(PairBox) : 0);
 }
 inline size_t rhs_lds_bytes(int cpl, int wpb)
 {
@@ -36,6 +38,10 @@ inline size_t rhs_lds_bytes(int cpl, int wpb)
 template <int CPL> hipError_t launch_step_cpl(const LaunchCfg &cfg, const StepArgs &A);
 template <int CPL> hipError_t launch_rhs_cpl(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt,
                                              double *aux);
+// split column: two waves per member, PAIR_CPL nodes per lane each, D in (64 PAIR_CPL, 128 PAIR_CPL]  (hc_inst.hip with
+// -DHC_INST_PAIR)
+constexpr int PAIR_CPL = 5;
+hipError_t launch_step_pair(const LaunchCfg &cfg, const StepArgs &A);
 #define HC_DECLARE_CPL(N)                                                                    \
     template <> hipError_t launch_step_cpl<N>(const LaunchCfg &cfg, const StepArgs &A);       \
     template <> hipError_t launch_rhs_cpl<N>(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt, \

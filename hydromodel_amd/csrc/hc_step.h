@@ -86,19 +86,22 @@ constexpr int LDS_BYTES = 160 * 1024;
 // The noise vector is read across lanes (cell j uses n_rnd[j-1]) and at every attempt: it is always in LDS.  (Round 1
 // dropped it from LDS for deep columns and rebuilt it per attempt; with the overflow region in place keeping it is
 // faster at every depth -- D = 401 +3 %, 541 +6 %, 581 +8 % -- and removes a second code path.)
-__host__ __device__ constexpr int lds_vectors(int cpl)      // how many of the twelve fit, four waves per workgroup
+// `halves` = 2: a column split over two waves (hc_device.h, Comm<2>) -- each wave holds 64 cpl nodes, the shared tables
+// cover both halves, and the workgroup's two mailboxes sit behind the waves' vectors.
+__host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1)   // how many of the twelve fit, four waves per workgroup
 {
     const int slots = 64 * cpl;
-    const int tables = NTAB * slots * 8 + 4 * slots;
-    const int n = ((LDS_BYTES - tables) / WAVES_PER_BLOCK - WAVE_SCRATCH * 8) / (slots * 8);
+    const int tables = (NTAB * slots * 8 + 4 * slots) * halves;
+    const int boxes = halves == 2 ? (WAVES_PER_BLOCK / 2) * (int)sizeof(PairBox) : 0;
+    const int n = ((LDS_BYTES - tables - boxes) / WAVES_PER_BLOCK - WAVE_SCRATCH * 8) / (slots * 8);
     return n < NVEC ? n : NVEC;
 }
-__host__ __device__ constexpr int lds_listed(int cpl)       // ... of the eleven vectors other than the noise
+__host__ __device__ constexpr int lds_listed(int cpl, int halves = 1)    // ... of the eleven vectors other than the noise
 {
-    const int n = lds_vectors(cpl) - 1;
+    const int n = lds_vectors(cpl, halves) - 1;
     return n < NVEC - 1 ? n : NVEC - 1;
 }
-__host__ __device__ constexpr int spill_vectors(int cpl) { return NVEC - lds_listed(cpl); }   // incl. V_Y0
+__host__ __device__ constexpr int spill_vectors(int cpl, int halves = 1) { return NVEC - lds_listed(cpl, halves); }   // incl. V_Y0
 // rank of a vector in the keep-in-LDS order D0..D5, Y, FP, D6, FAC, D7 (, Y0: never in LDS)
 __host__ __device__ constexpr int vec_rank(int v)
 {
@@ -107,10 +110,10 @@ __host__ __device__ constexpr int vec_rank(int v)
 
 // A wave's vectors: `lds` holds the first lds_listed(CPL) of the order above (then the noise vector, if it is in LDS),
 // `spill` the rest.  VEC is a compile-time id; the D-row accessors take the row as an unrolled loop index.
-template <int CPL>
+template <int CPL, int HALVES = 1>
 struct WaveVecs {
     static constexpr int SLOTS = WAVE * CPL;
-    static constexpr int N_LDS = lds_listed(CPL);
+    static constexpr int N_LDS = lds_listed(CPL, HALVES);
     double *lds;
     __attribute__((address_space(1))) double *spill;
     template <int VEC>
@@ -240,9 +243,9 @@ __device__ __forceinline__ double alpha_k(int k) { return ALPHA_TAB[k]; }
 __device__ __forceinline__ double error_const_k(int k) { return ERRC_TAB[k]; }
 
 // RMS norm of x[c]/scale[c] over the D valid nodes; is[c] = 1/scale[c]
-template <int CPL>
+template <int CPL, class CommT>
 __device__ __forceinline__ double rms_ratio(const double (&x)[CPL], const double (&is)[CPL], int lane, int D,
-                                            double inv_sqrt_d)
+                                            double inv_sqrt_d, CommT &comm)
 {
     // no node mask: every vector this is applied to is exactly 0 in the padding slots beyond the grid (state,
     // differences and dy/dt are kept 0 there), and 1/scale is finite there
@@ -254,14 +257,14 @@ __device__ __forceinline__ double rms_ratio(const double (&x)[CPL], const double
         const double r = x[c] * is[c];
         acc = fma(r, r, acc);
     }
-    return sqrt_pos(wave_sum(acc)) * inv_sqrt_d;
+    return sqrt_pos(comm.sum(acc)) * inv_sqrt_d;
 }
 
 // bdf.py change_D: D[:order+1] = (R(order,factor) @ R(order,1)).T @ D[:order+1].
 // R[i][j] = prod_{q=1..i} (q-1-factor*j)/q (R[0][j] = 1, R[i>0][0] = 0); lanes 0..35 build R and U = R(.,1)
 // in LDS, lanes 0..35 form RU, then every lane applies RU^T to its cells.
-template <int CPL, int ORDER>
-__device__ __forceinline__ void apply_RU(const WaveVecs<CPL> &W, const double *ru, int lane)
+template <int CPL, int ORDER, class WV>
+__device__ __forceinline__ void apply_RU(const WV &W, const double *ru, int lane)
 {
     constexpr int SLOTS = WAVE * CPL;
     double m[ORDER + 1][ORDER + 1];
@@ -304,8 +307,8 @@ __device__ __forceinline__ void change_D_init(double *ru, int lane)
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int CPL>
-__device__ __forceinline__ void change_D(const WaveVecs<CPL> &W, double *ru, int order, double factor, int lane)
+template <int CPL, class WV>
+__device__ __forceinline__ void change_D(const WV &W, double *ru, int order, double factor, int lane)
 {
     // R[i][j] = prod_{q=1..i} (q - 1 - factor j) / q on lanes 0..35 (cumprod of bdf.py compute_R), RU = R U on the
     // same lanes with all twelve operands read before the first multiply, then D[:order+1] = RU^T D[:order+1]
@@ -351,8 +354,8 @@ __device__ __forceinline__ void change_D(const WaveVecs<CPL> &W, double *ru, int
 
 // bdf.py _step_impl after acceptance, for a compile-time order: D[order+2] = d - D[order+1]; D[order+1] = d;
 // D[k] += D[k+1] for k = order..0.  All rows are read before any is written (independent LDS reads).
-template <int CPL, int ORDER>
-__device__ __forceinline__ void accept_update(const WaveVecs<CPL> &W, const double (&dd)[CPL], int lane, double (&d_ord)[CPL],
+template <int CPL, int ORDER, class WV>
+__device__ __forceinline__ void accept_update(const WV &W, const double (&dd)[CPL], int lane, double (&d_ord)[CPL],
                                               double (&d_ord2)[CPL])
 {
     constexpr int SLOTS = WAVE * CPL;
@@ -376,8 +379,8 @@ __device__ __forceinline__ void accept_update(const WaveVecs<CPL> &W, const doub
     }
 }
 // predictor: y_predict = sum_k D[k], psi = sum_{k>=1} gamma_k D[k] / alpha_order
-template <int CPL, int ORDER>
-__device__ __forceinline__ void predict(const WaveVecs<CPL> &W, int lane, double inv_alpha, double (&yp)[CPL],
+template <int CPL, int ORDER, class WV>
+__device__ __forceinline__ void predict(const WV &W, int lane, double inv_alpha, double (&yp)[CPL],
                                         double (&psiv)[CPL])
 {
     constexpr int SLOTS = WAVE * CPL;
@@ -399,23 +402,44 @@ __device__ __forceinline__ void predict(const WaveVecs<CPL> &W, int lane, double
 }
 
 // ---- lane-partitioned tridiagonal factorisation of A = I - cc*J -------------------------
-template <int CPL>
+// H = 2 (split column): each wave factorises ITS block of the matrix with the coupling across the cut removed -- the
+// upper half's last row loses its super-diagonal `couple` = c_last, the lower half's first row its sub-diagonal a_first --
+// and keeps the block's answer to a unit load at the cut, sp = T^-1 e_edge.  With g = couple * sp[edge] of either half,
+//   x_last(upper) = (z_last - g_u z_first) / (1 - g_u g_l),   x_first(lower) = z_first - g_l x_last,
+// and every row follows from its own block: x = z - couple * x_edge(other half) * sp.  One exchange per solve.
+template <int CPL, int H = 1>
 struct TriLU {
     double wf[CPL], wb[CPL], l[CPL], u[CPL], ib[CPL];
     double wx, invB, al[6], ga[6];
+    double sp[H == 2 ? CPL : 1];
+    double couple, g_up, g_lo, inv_den;
 };
 
-template <int CPL>
-__device__ __forceinline__ void lu_factor(TriLU<CPL> &F, const double (&jl)[CPL], const double (&jd)[CPL],
-                                          const double (&ju)[CPL], double cc, int lane, int D)
+template <int CPL, int H>
+__device__ __forceinline__ void lu_solve_block(const TriLU<CPL, H> &F, double (&x)[CPL], int lane);
+
+template <int CPL, class CommT>
+__device__ __forceinline__ void lu_factor(TriLU<CPL, CommT::H> &F, const double (&jl)[CPL], const double (&jd)[CPL],
+                                          const double (&ju)[CPL], double cc, int lane, int D, CommT &comm)
 {
+    constexpr int H = CommT::H;
+    const int hb = H == 2 ? comm.half * (WAVE * CPL) : 0;
     double a[CPL], b[CPL], cu[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
-        const bool v = lane * CPL + c < D;
+        const bool v = hb + lane * CPL + c < D;
         a[c] = v ? -cc * jl[c] : 0.0;
         b[c] = v ? 1.0 - cc * jd[c] : 1.0;
         cu[c] = v ? -cc * ju[c] : 0.0;
+    }
+    if constexpr (H == 2) {
+        if (comm.half == 0) {
+            F.couple = readlane_d(cu[CPL - 1], WAVE - 1);
+            cu[CPL - 1] = lane == WAVE - 1 ? 0.0 : cu[CPL - 1];
+        } else {
+            F.couple = readlane_d(a[0], 0);
+            a[0] = lane == 0 ? 0.0 : a[0];
+        }
     }
     // forward: remove the sub-diagonal inside the chunk; fill-in l[] couples to x_{s-1}
     F.l[0] = a[0];
@@ -469,10 +493,26 @@ __device__ __forceinline__ void lu_factor(TriLU<CPL> &F, const double (&jl)[CPL]
         U = ga * Up;
     }
     F.invB = fast_div(1.0, B);
+    if constexpr (H == 2) {
+        double e[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) e[c] = 0.0;
+        if (comm.half == 0) e[CPL - 1] = lane == WAVE - 1 ? 1.0 : 0.0;
+        else e[0] = lane == 0 ? 1.0 : 0.0;
+        lu_solve_block<CPL, H>(F, e, lane);
+#pragma unroll
+        for (int c = 0; c < CPL; c++) F.sp[c] = e[c];
+        const double mine[1] = {F.couple * (comm.half == 0 ? readlane_d(e[CPL - 1], WAVE - 1) : readlane_d(e[0], 0))};
+        double theirs[1];
+        comm.xchg(mine, theirs);
+        F.g_up = comm.half == 0 ? mine[0] : theirs[0];
+        F.g_lo = comm.half == 0 ? theirs[0] : mine[0];
+        F.inv_den = fast_div(1.0, 1.0 - F.g_up * F.g_lo);
+    }
 }
 
-template <int CPL>
-__device__ __forceinline__ void lu_solve(const TriLU<CPL> &F, double (&x)[CPL], int lane)
+template <int CPL, int H>
+__device__ __forceinline__ void lu_solve_block(const TriLU<CPL, H> &F, double (&x)[CPL], int lane)
 {
 #pragma unroll
     for (int c = 1; c < CPL; c++) x[c] -= F.wf[c] * x[c - 1];
@@ -494,6 +534,23 @@ __device__ __forceinline__ void lu_solve(const TriLU<CPL> &F, double (&x)[CPL], 
     x[CPL - 1] = xe;
 #pragma unroll
     for (int c = 0; c < CPL - 1; c++) x[c] = (x[c] - F.l[c] * xp - F.u[c] * xe) * F.ib[c];
+}
+
+template <int CPL, class CommT>
+__device__ __forceinline__ void lu_solve(const TriLU<CPL, CommT::H> &F, double (&x)[CPL], int lane, CommT &comm)
+{
+    lu_solve_block<CPL, CommT::H>(F, x, lane);
+    if constexpr (CommT::H == 2) {
+        const double mine[1] = {comm.half == 0 ? readlane_d(x[CPL - 1], WAVE - 1) : readlane_d(x[0], 0)};
+        double theirs[1];
+        comm.xchg(mine, theirs);
+        const double z_up = comm.half == 0 ? mine[0] : theirs[0], z_lo = comm.half == 0 ? theirs[0] : mine[0];
+        const double x_up = (z_up - F.g_up * z_lo) * F.inv_den;          // last unknown of the upper half
+        const double x_lo = z_lo - F.g_lo * x_up;                        // first unknown of the lower half
+        const double coef = F.couple * (comm.half == 0 ? x_lo : x_up);
+#pragma unroll
+        for (int c = 0; c < CPL; c++) x[c] = fma(-coef, F.sp[c], x[c]);
+    }
 }
 
 // _sparse_num_jac bookkeeping for ONE column j: max |f_new - f| over the stored rows j-1, j, j+1
@@ -525,27 +582,30 @@ enum Phase {
     C_SUCCESS, C_FAIL
 };
 
-template <int CPL, bool SPECIAL, int WPB, bool PREDICT>
+// HALVES = 2: a member's column is split over the waves 2p and 2p + 1 of the workgroup (Comm<2>, hc_device.h): SLOTS is
+// what ONE wave holds, the tables cover TSLOTS = 2 SLOTS slots, and each wave works on its half through `tabw` / `gtabw`.
+template <int CPL, bool SPECIAL, int WPB, bool PREDICT, int HALVES = 1>
 __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArgs A)
 {
     constexpr int SLOTS = WAVE * CPL;
+    constexpr int TSLOTS = SLOTS * HALVES;
     extern __shared__ double lds[];
     double *tab = lds;
-    signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB * SLOTS);     // group ids < 16: a byte each
-    double *wave_base = reinterpret_cast<double *>(gtab + 4 * SLOTS);
-    constexpr int NVEC_K = lds_vectors(CPL);
+    signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB * TSLOTS);     // group ids < 16: a byte each
+    double *wave_base = reinterpret_cast<double *>(gtab + 4 * TSLOTS);
+    constexpr int NVEC_K = lds_vectors(CPL, HALVES);
     static_assert(WPB == WAVES_PER_BLOCK, "four waves per workgroup");
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
     // [0] next member of the chunk, [1] its end (-1: no chunk left), [2] point whose tables are in LDS, [3] the chunk's point
-    volatile int *chunk_state = reinterpret_cast<volatile int *>(gtab + NGTAB * SLOTS);
+    volatile int *chunk_state = reinterpret_cast<volatile int *>(gtab + NGTAB * TSLOTS);
 #ifdef HC_SINGLE_POINT   // development builds: the scheduler of the multi-point mode compiled out (A/B timing)
     constexpr bool multi = false;
 #else
-    const bool multi = A.n_points > 1;
+    const bool multi = HALVES == 1 && A.n_points > 1;      // (the host never sends several points to the split-column kernel)
 #endif
     if (!multi)
-        for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
-    for (int k = threadIdx.x; k < NGTAB * SLOTS; k += WPB * WAVE) gtab[k] = (signed char)A.gtab[k];
+        for (int k = threadIdx.x; k < NTAB * TSLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
+    for (int k = threadIdx.x; k < NGTAB * TSLOTS; k += WPB * WAVE) gtab[k] = (signed char)A.gtab[k];
     if (threadIdx.x == 0) {
         chunk_state[0] = 0;
         chunk_state[1] = 0;
@@ -558,9 +618,29 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     // workgroup per CU); a wave that finishes its member takes the next one from a device-wide ticket,
     // so members of unequal cost never leave SIMDs idle behind a slow neighbour.  Exit: ticket >= N.
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int hb = HALVES == 2 ? (wave & 1) * SLOTS : 0;          // this wave's first node
+    const double *tabw = tab + hb;
+    const signed char *gtabw = gtab + hb;
     double *V = wave_base + (size_t)wave * (NVEC_K * SLOTS + WAVE_SCRATCH);
     double *ru = V + NVEC_K * SLOTS;
-    double *row0 = ru + 108;                    // f_new[group][row 0], <= 16 groups
+    // f_new[group][row 0], <= 16 groups: row 0 belongs to the upper half, the lower half reads it there
+    double *row0 = (HALVES == 2 && (wave & 1) ? ru - (NVEC_K * SLOTS + WAVE_SCRATCH) : ru) + 108;
+    Comm<HALVES> comm;
+    comm.half = HALVES == 2 ? (wave & 1) : 0;
+    // the partner wave's noise vector (the lower half's first cell uses n_rnd of the upper half's last node, its
+    // top-node cell n_rnd[0])
+    const double *nz_partner = V + (HALVES == 2 ? ((wave & 1) ? -1 : 1) * (NVEC_K * SLOTS + WAVE_SCRATCH) : 0) +
+                               lds_listed(CPL, HALVES) * SLOTS;
+    if constexpr (HALVES == 2) {
+        PairBox *boxes = reinterpret_cast<PairBox *>(wave_base + (size_t)WPB * (NVEC_K * SLOTS + WAVE_SCRATCH));
+        comm.lane = lane;
+        comm.k = 0;
+        comm.dead = false;
+        comm.fault = load_const(A.io).counters + 5;
+        comm.box = boxes + (wave >> 1);
+        if (lane < 2) comm.box->seq[lane] = 0;       // both halves write the same zeros, before the first exchange of either
+        __syncthreads();
+    }
     int *flags_lds = reinterpret_cast<int *>(ru + 124);   // per-lane column flags of the FD-Jacobian retry pass
 #ifdef HC_PROFILE
     unsigned long long *prof_lds = reinterpret_cast<unsigned long long *>(ru + 160);
@@ -568,10 +648,10 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     if (lane < 32) prof_lds[64 + lane] = 0;
     int prof_slot = 31;
 #endif
-    WaveVecs<CPL> W;
+    WaveVecs<CPL, HALVES> W;
     W.lds = V;
     W.spill = (__attribute__((address_space(1))) double *)A.wave_spill +
-              ((size_t)blockIdx.x * WPB + wave) * ((size_t)spill_vectors(CPL) * SLOTS);
+              ((size_t)blockIdx.x * WPB + wave) * ((size_t)spill_vectors(CPL, HALVES) * SLOTS);
     change_D_init(ru, lane);
     const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
@@ -582,9 +662,16 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     if (!multi) {
         const IoArgs io = load_const(A.io);
         unsigned long long ticket = 0;
-        if (lane == 0) ticket = atomicAdd(io.queue, 1ull);
+        if (lane == 0 && comm.half == 0) ticket = atomicAdd(io.queue, 1ull);
         member = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ticket >> 32)) << 32) |
                              (unsigned)__builtin_amdgcn_readfirstlane((int)ticket));
+        if constexpr (HALVES == 2) {       // the upper half draws the member, the lower half learns it
+            const double mine[1] = {(double)member};
+            double theirs[1];
+            comm.xchg(mine, theirs);
+            member = comm.half == 0 ? member : (long long)theirs[0];
+            if (comm.dead) break;          // (an exchange timed out: see Comm<2>::xchg; the host reports it)
+        }
         if (member >= A.n_members) break;
     } else {
         // Several parameter points: the four waves draw members of the workgroup's current chunk from an LDS counter.
@@ -640,7 +727,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     point = __builtin_amdgcn_readfirstlane(point);
     bool vnode[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; c++) vnode[c] = lane * CPL + c < D;
+    for (int c = 0; c < CPL; c++) vnode[c] = hb + lane * CPL + c < D;
     // FD-Jacobian column groups of this lane's nodes and of their neighbours.  Up to CPL = 5 they sit in 3 CPL registers
     // for the kernel's lifetime; deep columns (already spilling to scratch) read them from LDS at the top of each
     // Jacobian phase instead (HC_GROUPS: a batch of byte loads through a pointer made opaque at that point, so that
@@ -656,20 +743,20 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     if (!DEEP) {
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-            gs_keep[c] = gtab[G_SELF * SLOTS + c * WAVE + lane];
-            gp_keep[c] = gtab[G_PREV * SLOTS + c * WAVE + lane];
-            gn_keep[c] = gtab[G_NEXT * SLOTS + c * WAVE + lane];
+            gs_keep[c] = gtabw[G_SELF * TSLOTS + c * WAVE + lane];
+            gp_keep[c] = gtabw[G_PREV * TSLOTS + c * WAVE + lane];
+            gn_keep[c] = gtabw[G_NEXT * TSLOTS + c * WAVE + lane];
         }
     }
 #define HC_GROUPS()                                                                          \
     int gs[CPL], gp[CPL], gn[CPL];                                                           \
     {                                                                                        \
-        auto gq = (const __attribute__((address_space(3))) signed char *)gtab;               \
+        auto gq = (const __attribute__((address_space(3))) signed char *)gtabw;              \
         if (DEEP) asm volatile("" : "+v"(gq));                                               \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) {                                    \
-            gs[c] = DEEP ? (int)gq[G_SELF * SLOTS + c * WAVE + lane] : gs_keep[c];           \
-            gp[c] = DEEP ? (int)gq[G_PREV * SLOTS + c * WAVE + lane] : gp_keep[c];           \
-            gn[c] = DEEP ? (int)gq[G_NEXT * SLOTS + c * WAVE + lane] : gn_keep[c];           \
+            gs[c] = DEEP ? (int)gq[G_SELF * TSLOTS + c * WAVE + lane] : gs_keep[c];          \
+            gp[c] = DEEP ? (int)gq[G_PREV * TSLOTS + c * WAVE + lane] : gp_keep[c];          \
+            gn[c] = DEEP ? (int)gq[G_NEXT * TSLOTS + c * WAVE + lane] : gn_keep[c];          \
         }                                                                                    \
     }
     // state -> LDS
@@ -678,7 +765,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         const IoArgs io = load_const(A.io);
 #pragma unroll
         for (int c = 0; c < CPL; c++)
-            W.template st<V_Y>(c * WAVE + lane, vnode[c] ? io.psi[member * D + lane * CPL + c] : 0.0);
+            W.template st<V_Y>(c * WAVE + lane, vnode[c] ? io.psi[member * D + hb + lane * CPL + c] : 0.0);
         if (!A.host_noise) nscale = io.nscale[member];
     }
     int fresh_seen = 0;
@@ -727,7 +814,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                 if (multi && !A.host_noise) gid = io.point_base[point] + (member - (long long)point * A.members_per_point);
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
-                    const int i = lane * CPL + c;
+                    const int i = hb + lane * CPL + c;
                     double z = 0.0;
                     if (vnode[c]) {
                         if (A.host_noise) {
@@ -761,18 +848,30 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                 // scaled noise per evaluated cell: midpoint j uses n_rnd[max(j-1,0)]; the virtual
                 // top-node cell (lane 63, last slot) uses n_rnd[0]   
                 double rnd[CPL];
+                if constexpr (HALVES == 2) {       // both halves' noise vectors are in place before either reads across the cut
+                    const double mine[1] = {0.0};
+                    double theirs[1];
+                    comm.xchg(mine, theirs);
+                }
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
-                    const int i = lane * CPL + c;
+                    const int i = hb + lane * CPL + c;
                     int idx = i >= 1 ? i - 1 : 0;
                     idx = (i < D - 1) ? idx : 0;
-                    const double z = W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL);
-                    rnd[c] = tab[T_NOISEC * SLOTS + c * WAVE + lane] * z;
+                    double z;
+                    if constexpr (HALVES == 2) {
+                        const int wl = idx / CPL, sl = (idx % CPL) * WAVE + (wl & (WAVE - 1));
+                        const double own = W.template ld<V_NZ>(sl), other = nz_partner[sl];
+                        z = (wl >> 6) == comm.half ? own : other;
+                    } else {
+                        z = W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL);
+                    }
+                    rnd[c] = tabw[T_NOISEC * TSLOTS + c * WAVE + lane] * z;
                 }
                 // ================= one BDF integration over [t0, tf] =================
                 double ycur[CPL], f[CPL], yp[CPL], psiv[CPL], scl[CPL] /* 1/scale */, dd[CPL];
                 double jl[CPL], jd[CPL], ju[CPL], hj[CPL];
-                TriLU<CPL> F;
+                TriLU<CPL, HALVES> F;
                 double t = t0, h_abs = 0.0, h0 = 0.0, t_new = t0, cc = 0.0, min_step = 0.0;
                 double dy_norm_old = -1.0, safety = 0.0, error_norm = 0.0;
                 int order = 1, n_equal = 0, have_lu = 0, current_jac = 0, newton_k = 0, n_iter = 0;
@@ -816,8 +915,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         }
                     }
 #endif
-                    if (++guard > A.max_phase_iterations) {
-                        if (lane == 0) {
+                    if (++guard > A.max_phase_iterations || comm.dead) {
+                        if (lane == 0 && comm.half == 0) {
                             const IoArgs iog = load_const(A.io);
                             atomicAdd(&iog.counters[2], 1ull);
                             // where it happened (last writer wins): global member id << 24 | forcing row
@@ -829,7 +928,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     }
                     if (phase < C_SUCCESS) {
                         HC_STAMP(16);   // RHS prologue (midpoints); rhs_eval stamps its own regions 24..29
-                        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf HC_RHS_PROF_ARG);
+                        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
                         HC_STAMP(17);   // after the RHS: dispatch to the phase block
                     }
                     // Phases run in topological order inside ONE loop iteration: a block that hands over to a
@@ -849,8 +948,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             W.template st<V_FP>(slot, f[c]);    // base f of the first Jacobian
                             scl[c] = fast_div(1.0, ATOL + fabs(y0v[c]) * RTOL);
                         }
-                        const double d0 = rms_ratio<CPL>(y0v, scl, lane, D, inv_sqrt_d);
-                        const double d1 = rms_ratio<CPL>(f, scl, lane, D, inv_sqrt_d);
+                        const double d0 = rms_ratio<CPL>(y0v, scl, lane, D, inv_sqrt_d, comm);
+                        const double d1 = rms_ratio<CPL>(f, scl, lane, D, inv_sqrt_d, comm);
                         h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
                         h0 = fmin(h0, fabs(tf - t0));
                         cc = d1;                              // carried to PH_F1
@@ -870,7 +969,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #pragma unroll
                         for (int c = 0; c < CPL; c++) df[c] = f[c] - W.template ld<V_FP>(c * WAVE + lane);
                         const double d1 = cc;
-                        const double d2 = rms_ratio<CPL>(df, scl, lane, D, inv_sqrt_d) / h0;
+                        const double d2 = rms_ratio<CPL>(df, scl, lane, D, inv_sqrt_d, comm) / h0;
                         double h1;
                         if (d1 <= 1e-15 && d2 <= 1e-15)
                             h1 = fmax(1e-6, h0 * 1e-3);
@@ -898,9 +997,9 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #pragma unroll
                             for (int c = 0; c < CPL; c++) dy[c] = cc * f[c] - psiv[c] - dd[c];   // 0 in the padding slots
                             HC_STAMP(20);
-                            lu_solve<CPL>(F, dy, lane);
+                            lu_solve<CPL>(F, dy, lane, comm);
                             HC_STAMP(21);
-                            const double dy_norm = rms_ratio<CPL>(dy, scl, lane, D, inv_sqrt_d);
+                            const double dy_norm = rms_ratio<CPL>(dy, scl, lane, D, inv_sqrt_d, comm);
                             HC_STAMP(22);
                             // scipy: `if not np.all(np.isfinite(f)): break`.  A non-finite f makes the solve and its
                             // norm non-finite, and the iterate is left untouched either way.
@@ -965,15 +1064,15 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         double fb[CPL];
 #pragma unroll
                         for (int c = 0; c < CPL; c++) fb[c] = W.template ld<V_FP>(c * WAVE + lane);
-                        const double fbU0 = shfl_up1(fb[CPL - 1], lane, 0.0), fbD0 = shfl_down1(fb[0], lane, 0.0);
-                        const double fU0 = shfl_up1(f[CPL - 1], lane, 0.0), fD0 = shfl_down1(f[0], lane, 0.0);
-                        const double fnU0 = shfl_up1(ju[CPL - 1], lane, 0.0), fnD0 = shfl_down1(jl[0], lane, 0.0);
-                        const double fb_row0 = readlane_d(fb[0], 0), f_row0 = readlane_d(f[0], 0);
+                        const double fbU0 = comm.up1(fb[CPL - 1], lane, 0.0), fbD0 = comm.down1(fb[0], lane, 0.0);
+                        const double fU0 = comm.up1(f[CPL - 1], lane, 0.0), fD0 = comm.down1(f[0], lane, 0.0);
+                        const double fnU0 = comm.up1(ju[CPL - 1], lane, 0.0), fnD0 = comm.down1(jl[0], lane, 0.0);
+                        const double fb_row0 = comm.first_row(fb[0]), f_row0 = comm.first_row(f[0]);
                         int flags = flags_lds[lane];
                         double upd[CPL];
 #pragma unroll
                         for (int c = 0; c < CPL; c++) {
-                            const int i = lane * CPL + c, slot = c * WAVE + lane;
+                            const int i = hb + lane * CPL + c, slot = c * WAVE + lane;
                             const bool hasU = i >= 1, hasD = i < D - 1;
                             const double fbU = c == 0 ? fbU0 : fb[c > 0 ? c - 1 : 0];
                             const double fbD = c == CPL - 1 ? fbD0 : fb[c < CPL - 1 ? c + 1 : c];
@@ -999,7 +1098,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             }
                         }
                         flags_lds[lane] = flags;
-                        const double updU0 = shfl_up1(upd[CPL - 1], lane, 0.0), updD0 = shfl_down1(upd[0], lane, 0.0);
+                        const double updU0 = comm.up1(upd[CPL - 1], lane, 0.0), updD0 = comm.down1(upd[0], lane, 0.0);
 #pragma unroll
                         for (int c = 0; c < CPL; c++) {
                             const double uU = c == 0 ? updU0 : upd[c > 0 ? c - 1 : 0];
@@ -1048,7 +1147,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             HC_SUB(63);
                             // f holds fun(y + h * [group == g]); scatter into the three per-row slots
                             const double r0v = readlane_d(f[0], 0);
-                            if (lane == 0) row0[g] = r0v;
+                            if (lane == 0 && comm.half == 0) row0[g] = r0v;
 #pragma unroll
                             for (int c = 0; c < CPL; c++) {
                                 jl[c] = (gp[c] == g) ? f[c] : jl[c];
@@ -1074,16 +1173,16 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         double fb[CPL];
 #pragma unroll
                         for (int c = 0; c < CPL; c++) fb[c] = W.template ld<V_FP>(c * WAVE + lane);
-                        const double fbU0 = shfl_up1(fb[CPL - 1], lane, 0.0), fnU0 = shfl_up1(ju[CPL - 1], lane, 0.0);
-                        const double fbD0 = shfl_down1(fb[0], lane, 0.0), fnD0 = shfl_down1(jl[0], lane, 0.0);
-                        const double hU0 = shfl_up1(hj[CPL - 1], lane, 1.0), hD0 = shfl_down1(hj[0], lane, 1.0);
-                        const double fb_row0 = readlane_d(fb[0], 0);
+                        const double fbU0 = comm.up1(fb[CPL - 1], lane, 0.0), fnU0 = comm.up1(ju[CPL - 1], lane, 0.0);
+                        const double fbD0 = comm.down1(fb[0], lane, 0.0), fnD0 = comm.down1(jl[0], lane, 0.0);
+                        const double hU0 = comm.up1(hj[CPL - 1], lane, 1.0), hD0 = comm.down1(hj[0], lane, 1.0);
+                        const double fb_row0 = comm.first_row(fb[0]);
                         const int old_flags = jac_stage ? flags_lds[lane] : 0;     // bit c: small, bit 16+c: factor done
                         int small_bits = 0, my_groups = 0;
                         double njl[CPL], njd[CPL], nju[CPL], nfac[CPL];
 #pragma unroll
                         for (int c = 0; c < CPL; c++) {
-                            const int i = lane * CPL + c;
+                            const int i = hb + lane * CPL + c;
                             const double fbU = c == 0 ? fbU0 : fb[c > 0 ? c - 1 : 0];
                             const double fnU = c == 0 ? fnU0 : ju[c > 0 ? c - 1 : 0];
                             const double fbD = c == CPL - 1 ? fbD0 : fb[c < CPL - 1 ? c + 1 : c];
@@ -1109,16 +1208,16 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             njd[c] = vnode[c] ? fast_div(jd[c] - fb[c], hj[c]) : 0.0;
                             nju[c] = hasD ? fast_div(ju[c] - fb[c], hD) : 0.0;
                         }
-                        if (jac_stage == 0 && __any(small_bits != 0)) {
+                        if (jac_stage == 0 && comm.any(small_bits != 0)) {
                             // rare: some column moved f by less than EPS^0.875 of its size -> retry those columns
                             // with a 10x step, group by group (num_jac's diff_too_small branch); nothing committed yet
                             redo_mask = 0;
                             for (int q = 0; q < A.n_groups; q++)
                                 if (__any((my_groups >> q) & 1)) redo_mask |= 1 << q;
-                            redo_mask = uniform_i(redo_mask);
+                            redo_mask = comm.or_bits(uniform_i(redo_mask));
                             flags_lds[lane] = small_bits;
                             __builtin_amdgcn_wave_barrier();
-                            if (lane == 0) atomicAdd(&load_const(A.io).counters[0], 1ull);
+                            if (lane == 0 && comm.half == 0) atomicAdd(&load_const(A.io).counters[0], 1ull);
                             jac_stage = 1;
                             g = __ffs(redo_mask) - 1;
 #pragma unroll
@@ -1165,7 +1264,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             scl[c] = fast_div(1.0, ATOL + RTOL * fabs(ycur[c]));
                             e[c] = ec * dd[c];
                         }
-                        error_norm = rms_ratio<CPL>(e, scl, lane, D, inv_sqrt_d);
+                        error_norm = rms_ratio<CPL>(e, scl, lane, D, inv_sqrt_d, comm);
                         if (error_norm > 1.0) {
                             const double factor = fmax(0.2, safety * exp_mid(-log_pos(error_norm) / (double)(order + 1)));
                             h_abs *= factor;
@@ -1207,8 +1306,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                 ep[c] = ecp * d_ord2[c];
                             }
                             double nm = INFINITY, np_ = INFINITY;
-                            if (order > 1) nm = rms_ratio<CPL>(em, scl, lane, D, inv_sqrt_d);
-                            if (order < MAX_ORDER) np_ = rms_ratio<CPL>(ep, scl, lane, D, inv_sqrt_d);
+                            if (order > 1) nm = rms_ratio<CPL>(em, scl, lane, D, inv_sqrt_d, comm);
+                            if (order < MAX_ORDER) np_ = rms_ratio<CPL>(ep, scl, lane, D, inv_sqrt_d, comm);
                             // three pow() in three lanes at once
                             const double en = lane == 0 ? nm : (lane == 1 ? error_norm : np_);
                             // error_norms ** (-1 / (order + k)), k = 0, 1, 2: three lanes at once
@@ -1278,7 +1377,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         HC_STAMP(C_NEWTON_BEGIN);
                         if (!have_lu) {
                             HC_STAMP(23);
-                            lu_factor<CPL>(F, jl, jd, ju, cc, lane, D);
+                            lu_factor<CPL>(F, jl, jd, ju, cc, lane, D, comm);
                             HC_STAMP(C_NEWTON_BEGIN);
                             have_lu = 1;
                             nlu++;
@@ -1320,17 +1419,17 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                        (DEEPY ? W.template ld<V_Y0>(c * WAVE + lane) : yrow0[DEEPY ? 0 : c]);
                     sq = fma(dlt, dlt, sq);
                 }
-                spin_mse = wave_sum(sq) / (double)D;
+                spin_mse = comm.sum(sq) / (double)D;
             }
             failed_row = failed;
             if (failed) {
                 nz_is_base = false;
                 const IoArgs io = load_const(A.io);
-                if (lane == 0) atomicAdd(&io.counters[1], (unsigned long long)failed);
+                if (lane == 0 && comm.half == 0) atomicAdd(&io.counters[1], (unsigned long long)failed);
                 if (!refresh && A.host_noise) {
 #pragma unroll
                     for (int c = 0; c < CPL; c++)
-                        if (vnode[c]) io.base_noise[member * D + lane * CPL + c] = W.template ld<V_NZ>(c * WAVE + lane);
+                        if (vnode[c]) io.base_noise[member * D + hb + lane * CPL + c] = W.template ld<V_NZ>(c * WAVE + lane);
                 }
             }
             if (refresh) fresh_seen++;
@@ -1345,7 +1444,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             yv[c] = W.template ld<V_Y>(c * WAVE + lane);
             unsat[c] = vnode[c] && !(yv[c] >= psi_sat_m);
         }
-        const int istar = deepest_true<CPL>(unsat);
+        int istar = deepest_true<CPL>(unsat);
+        if constexpr (HALVES == 2) istar = comm.max_int(istar < 0 ? -1 : hb + istar);
         int w = istar < 0 ? 0 : istar + 1;
         w = w < D - 1 ? w : D - 1;
         if (skip) w = 0;
@@ -1355,12 +1455,12 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             const double abs_error = fabs(A.spin_zwtd - (A.spin_z0 + (double)w * A.spin_dz));
             const bool stop = (abs_error <= 2.0 * A.spin_dz) && (spin_mse <= 0.01);
             if (stop || r == A.n_rows - 1) {
-                if (lane == 0) load_const(A.io).spin_iters[member] = stop ? r + 1 : -(r + 1);
+                if (lane == 0 && comm.half == 0) load_const(A.io).spin_iters[member] = stop ? r + 1 : -(r + 1);
                 break;
             }
         } else {
             const IoArgs io = load_const(A.io);
-            if (lane == 0) {
+            if (lane == 0 && comm.half == 0) {
                 io.wtd_u16[(size_t)r * A.n_members + member] = (unsigned short)w;
                 if (io.stats) {
                     int *s = io.stats + ((size_t)r * A.n_members + member) * 6;
@@ -1371,9 +1471,9 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
                     if (vnode[c])
-                        io.psi_rows[((size_t)r * A.n_members + member) * D + lane * CPL + c] = skip ? 0.0 : yv[c];
+                        io.psi_rows[((size_t)r * A.n_members + member) * D + hb + lane * CPL + c] = skip ? 0.0 : yv[c];
             }
-            if (io.diag && lane == 0) {
+            if (io.diag && lane == 0 && comm.half == 0) {
                 io.diag[((size_t)r * A.n_members + member) * 2 + 0] = skip ? 0.0 : diag_tr;
                 io.diag[((size_t)r * A.n_members + member) * 2 + 1] = skip ? 0.0 : diag_lf;
             }
@@ -1383,8 +1483,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         const IoArgs io = load_const(A.io);
 #pragma unroll
         for (int c = 0; c < CPL; c++)
-            if (vnode[c]) io.psi[member * D + lane * CPL + c] = W.template ld<V_Y>(c * WAVE + lane);
-        if (!A.host_noise && lane == 0) io.nscale[member] = nscale;
+            if (vnode[c]) io.psi[member * D + hb + lane * CPL + c] = W.template ld<V_Y>(c * WAVE + lane);
+        if (!A.host_noise && lane == 0 && comm.half == 0) io.nscale[member] = nscale;
         if (multi && lane == 0) atomicAdd(&io.point_cost[point], (unsigned long long)cost_nfev);
 #ifdef HC_PROFILE
         __builtin_amdgcn_wave_barrier();

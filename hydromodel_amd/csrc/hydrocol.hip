@@ -89,6 +89,13 @@ struct hc_handle {
     std::vector<ColumnDev> P_host;
     std::vector<double> tab_host, node_host;
     bool points_dirty = false;
+    // split column (two waves per member, hc_device.h Comm<2>): columns of 513..640 nodes with one parameter point and
+    // the root zone inside the upper half; its own slot layout of the tables (point 0 only)
+    bool pair_ok = false, no_split = false;      // HYDROCOL_SPLIT_COLUMN=0 keeps the one-wave kernels (A/B, cross-checks)
+    std::vector<double> tab_pair_host;
+    DevBuf<double> tab_pair;
+    DevBuf<int> gtab_pair;
+    bool use_pair() const { return pair_ok && !no_split && n_points == 1; }
     int chunk_members = 0;       // HYDROCOL_CHUNK_MEMBERS (0: derived from the member count)
     DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
     DevBuf<double> wave_spill;   // per-wave vectors of deep columns that do not fit in LDS (hc_step.h WaveVecs)
@@ -346,10 +353,20 @@ LaunchCfg launch_cfg(hc_handle *h, unsigned grid)
 int launch_step(hc_handle *h, const StepArgs &A)
 {
     const int wpb = wpb_of(h->cpl);
+    HIP_TRY(hipMemsetAsync(h->counters.p + 63, 0, sizeof(unsigned long long), h->stream));
+    if (h->use_pair()) {
+        // split column: a workgroup runs two members at a time, two waves each
+        const long long want = (A.n_members + wpb / 2 - 1) / (wpb / 2);
+        const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->n_cu);
+        StepArgs B = A;
+        B.tab = h->tab_pair.p;
+        B.gtab = h->gtab_pair.p;
+        HIP_TRY(launch_step_pair(launch_cfg(h, grid), B));
+        return HC_OK;
+    }
     // persistent grid: LDS admits one workgroup per CU; fewer workgroups when there are fewer members
     const long long want = (A.n_members + wpb - 1) / wpb;
     const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->n_cu);
-    HIP_TRY(hipMemsetAsync(h->counters.p + 63, 0, sizeof(unsigned long long), h->stream));
     bool known = false;
     const hipError_t err = launch_step_cpl_any(h->cpl, known, launch_cfg(h, grid), A);
     if (!known) return unknown_depth(h);
@@ -390,6 +407,10 @@ int fill_args(hc_handle *h, StepArgs &A)
     if (h->points_dirty) {
         if (h->tab.ensure(h->tab_host.size()) || h->node_tabs.ensure(h->node_host.size())) return HC_ERR_DEVICE;
         HIP_TRY(hipMemcpy(h->tab.p, h->tab_host.data(), h->tab_host.size() * 8, hipMemcpyHostToDevice));
+        if (h->pair_ok) {
+            if (h->tab_pair.ensure(h->tab_pair_host.size())) return HC_ERR_DEVICE;
+            HIP_TRY(hipMemcpy(h->tab_pair.p, h->tab_pair_host.data(), h->tab_pair_host.size() * 8, hipMemcpyHostToDevice));
+        }
         HIP_TRY(hipMemcpy(h->node_tabs.p, h->node_host.data(), h->node_host.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->Pdev.p, h->P_host.data(), (size_t)NP * sizeof(ColumnDev), hipMemcpyHostToDevice));
         h->points_dirty = false;
@@ -414,13 +435,15 @@ int fill_args(hc_handle *h, StepArgs &A)
     }
     {
         // deep columns: room for the per-wave vectors LDS cannot hold, for every wave of the persistent grid
-        const size_t cnt = (size_t)h->n_cu * WAVES_PER_BLOCK * spill_vectors(h->cpl) * (size_t)h->slots;
+        const size_t per_wave = std::max((size_t)spill_vectors(h->cpl) * (size_t)h->slots,
+                                         (size_t)spill_vectors(PAIR_CPL, 2) * (size_t)(WAVE * PAIR_CPL));
+        const size_t cnt = (size_t)h->n_cu * WAVES_PER_BLOCK * per_wave;
         if (h->wave_spill.ensure(cnt)) return HC_ERR_DEVICE;
         A.wave_spill = h->wave_spill.p;
     }
     A.P = h->Pdev.p;
     A.io = h->iodev.p;
-    A.tab = h->tab.p;
+    A.tab = h->tab.p;          // (launch_step switches to the split-column tables)
     A.gtab = h->gtab.p;
     A.n_members = h->n_members;
     A.D = h->P.D;
@@ -517,6 +540,7 @@ int hc_create(int device_ordinal, hc_handle **out)
     if (rpl && atoi(rpl) > 0) h->rows_per_launch = atoi(rpl);
     if (const char *sg = getenv("HYDROCOL_STRICT_GUARD")) h->strict_guard = atoi(sg) != 0;
     if (const char *po = getenv("HYDROCOL_POINT_ORDER")) h->fixed_order = strcmp(po, "fixed") == 0;
+    if (const char *sc = getenv("HYDROCOL_SPLIT_COLUMN")) h->no_split = atoi(sc) == 0;
     if (const char *mi = getenv("HYDROCOL_DEBUG_MAX_ITER"))    // test hook: forces abandoned attempts
         if (atoi(mi) > 0) h->max_phase_iterations = atoi(mi);
     const char *jr = getenv("HYDROCOL_DEBUG_JAC_REJECT");   // test hook: exercises num_jac's retry branch
@@ -536,6 +560,7 @@ int hc_destroy(hc_handle *h)
     h->wave_spill.release();
     h->spin_iters.release();
     h->trace.release();
+    h->tab_pair.release(); h->gtab_pair.release();
     h->gtab.release(); h->wtd_obs.release(); h->draw_idx.release(); h->stats.release(); h->scratch_i.release();
     h->Pdev.release(); h->iodev.release();
     h->point_base.release(); h->point_order.release(); h->point_cost.release();
@@ -575,36 +600,50 @@ static int build_point(hc_handle *h, const hc_column_params *p, const double *no
     P.predict_low = std::min(D - 2, std::max(0, (D - 2) - (p->sat_cells - 1)));
     P.predict_first = (1 - (p->sat_cells - 1)) >= 1 ? 1 : 0;
 
-    const int M = D - 1, S = h->slots, cpl = h->cpl;
-    std::vector<double> tab((size_t)NTAB * S);
-    auto put = [&](int slot, double por, double fc, double wlt, double root, double meank, double noisec) {
-        const double mk = meank == 0.0 ? 1.0e-7 : meank;   // utilities.py:50
-        tab[(size_t)T_POR * S + slot] = por;
-        tab[(size_t)T_FC * S + slot] = fc;
-        tab[(size_t)T_WLT * S + slot] = wlt;
-        tab[(size_t)T_ROOT * S + slot] = root;
-        tab[(size_t)T_LOGM * S + slot] = std::log(mk);
-        tab[(size_t)T_INVM2 * S + slot] = 1.0 / (mk * mk);
-        tab[(size_t)T_NOISEC * S + slot] = noisec;
-        tab[(size_t)T_VALID * S + slot] = 1.0;
-        const double d1 = por - wlt;                       // tree_roots.py:235-238
-        tab[(size_t)T_INVD1 * S + slot] = 1.0 / (d1 == 0.0 ? 1.0 : d1);
+    const int M = D - 1;
+    // Slot tables for `halves` waves per member with `cpl` nodes per lane: node / midpoint i sits with wide lane
+    // wl = i / cpl, cell c = i % cpl, i.e. in wave wl / 64, slot c * 64 + wl % 64 of that wave's 64 cpl slots.
+    auto layout = [&](int cpl, int halves, std::vector<double> &tab) {
+        const int SW = WAVE * cpl, S = SW * halves;
+        tab.assign((size_t)NTAB * S, 0.0);
+        auto put = [&](int slot, double por, double fc, double wlt, double root, double meank, double noisec) {
+            const double mk = meank == 0.0 ? 1.0e-7 : meank;   // utilities.py:50
+            tab[(size_t)T_POR * S + slot] = por;
+            tab[(size_t)T_FC * S + slot] = fc;
+            tab[(size_t)T_WLT * S + slot] = wlt;
+            tab[(size_t)T_ROOT * S + slot] = root;
+            tab[(size_t)T_LOGM * S + slot] = std::log(mk);
+            tab[(size_t)T_INVM2 * S + slot] = 1.0 / (mk * mk);
+            tab[(size_t)T_NOISEC * S + slot] = noisec;
+            tab[(size_t)T_VALID * S + slot] = 1.0;
+            const double d1 = por - wlt;                       // tree_roots.py:235-238
+            tab[(size_t)T_INVD1 * S + slot] = 1.0 / (d1 == 0.0 ? 1.0 : d1);
+        };
+        for (int wl = 0; wl < WAVE * halves; wl++)
+            for (int c = 0; c < cpl; c++) {
+                const int i = wl * cpl + c, slot = (wl / WAVE) * SW + c * WAVE + wl % WAVE;
+                if (i < M)
+                    put(slot, mid_tabs[i], mid_tabs[M + i], mid_tabs[2 * M + i], mid_tabs[3 * M + i],
+                        mid_tabs[4 * M + i], mid_tabs[5 * M + i]);
+                else
+                    put(slot, 0.3, 0.2, 0.1, 0.0, 1.0, 0.0);    // padding cell: benign, results masked
+                if (i >= M) tab[(size_t)T_VALID * S + slot] = 0.0;
+            }
+        // virtual top-node cell in the always-free last slot of the last lane (of the last wave)
+        const int top = (halves - 1) * SW + (cpl - 1) * WAVE + (WAVE - 1);
+        put(top, node_tabs[0], 0.2, 0.1, 0.0, node_tabs[D + 0], node_tabs[2 * D + 0]);
+        tab[(size_t)T_VALID * S + top] = 0.0;                   // its C / flux never enter the assembly
     };
-    for (int lane = 0; lane < WAVE; lane++)
-        for (int c = 0; c < cpl; c++) {
-            const int i = lane * cpl + c, slot = c * WAVE + lane;
-            if (i < M)
-                put(slot, mid_tabs[i], mid_tabs[M + i], mid_tabs[2 * M + i], mid_tabs[3 * M + i],
-                    mid_tabs[4 * M + i], mid_tabs[5 * M + i]);
-            else
-                put(slot, 0.3, 0.2, 0.1, 0.0, 1.0, 0.0);    // padding cell: benign, results masked
-            if (i >= M) tab[(size_t)T_VALID * S + slot] = 0.0;
-        }
-    // virtual top-node cell in the always-free slot (lane 63, c = cpl-1)
-    put((cpl - 1) * WAVE + (WAVE - 1), node_tabs[0], 0.2, 0.1, 0.0, node_tabs[D + 0], node_tabs[2 * D + 0]);
-    tab[(size_t)T_VALID * S + (cpl - 1) * WAVE + (WAVE - 1)] = 0.0;   // its C / flux never enter the assembly
+    std::vector<double> tab;
+    layout(h->cpl, 1, tab);
     for (double v : tab)
         if (!std::isfinite(v)) return fail(HC_ERR_ARG, "a column table entry is not finite");
+    if (first) {
+        // split column: 513..640 nodes, the root zone (cells 1..n_root_int) inside the upper half
+        h->pair_ok = D > WAVE * 8 && D <= 2 * WAVE * PAIR_CPL && p->n_root_int <= WAVE * PAIR_CPL - 1;
+        h->tab_pair_host.clear();
+        if (h->pair_ok) layout(PAIR_CPL, 2, h->tab_pair_host);
+    }
     const bool special = (p->model == HC_MODEL_VRETTAS_FUNG && p->n == 2.0 && p->m == 0.5 && p->lambda_exp == 1.0);
     if (first) {
         h->P_host.clear(); h->tab_host.clear(); h->node_host.clear();
@@ -642,19 +681,28 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
     h->have_column = false;
     int rc = build_point(h, p, node_tabs, mid_tabs, true);
     if (rc) return rc;
-    const int S = h->slots;
-    std::vector<int> gt((size_t)NGTAB * S, -1);
-    for (int lane = 0; lane < WAVE; lane++)
-        for (int c = 0; c < cpl; c++) {
-            const int i = lane * cpl + c, slot = c * WAVE + lane;
-            if (i < D) {
-                gt[(size_t)G_SELF * S + slot] = groups[i];
-                gt[(size_t)G_PREV * S + slot] = i >= 1 ? groups[i - 1] : -1;
-                gt[(size_t)G_NEXT * S + slot] = i < D - 1 ? groups[i + 1] : -1;
+    auto group_layout = [&](int cpl_, int halves, std::vector<int> &gt) {
+        const int SW = WAVE * cpl_, S = SW * halves;
+        gt.assign((size_t)NGTAB * S, -1);
+        for (int wl = 0; wl < WAVE * halves; wl++)
+            for (int c = 0; c < cpl_; c++) {
+                const int i = wl * cpl_ + c, slot = (wl / WAVE) * SW + c * WAVE + wl % WAVE;
+                if (i < D) {
+                    gt[(size_t)G_SELF * S + slot] = groups[i];
+                    gt[(size_t)G_PREV * S + slot] = i >= 1 ? groups[i - 1] : -1;
+                    gt[(size_t)G_NEXT * S + slot] = i < D - 1 ? groups[i + 1] : -1;
+                }
             }
-        }
+    };
+    std::vector<int> gt;
+    group_layout(cpl, 1, gt);
     if (h->gtab.ensure(gt.size())) return HC_ERR_DEVICE;
     HIP_TRY(hipMemcpy(h->gtab.p, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
+    if (h->pair_ok) {
+        group_layout(PAIR_CPL, 2, gt);
+        if (h->gtab_pair.ensure(gt.size())) return HC_ERR_DEVICE;
+        HIP_TRY(hipMemcpy(h->gtab_pair.p, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
+    }
     h->have_column = true;
     return HC_OK;
 }
@@ -930,8 +978,10 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
                                  [&](int x, int y) { return cost[(size_t)x] > cost[(size_t)y]; });
         }
     }
-    unsigned long long cnt[4];
+    unsigned long long cnt[6];
     HIP_TRY(hipMemcpy(cnt, h->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+    if (cnt[5] != 0)
+        return fail(HC_ERR_DEVICE, "split-column kernel: %llu mailbox exchanges timed out (internal error; results are invalid)", cnt[5]);
     // An attempt that exhausts the kernel's iteration budget is abandoned like a solve that gave up (the x0.8
     // retry rule applies); it is counted ([2], last place in [3]) and only fatal on request.
     if (cnt[2] != 0 && h->strict_guard)
@@ -970,8 +1020,10 @@ int hc_spinup(hc_handle *h, hc_spinup_args *a)
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     a->kernel_ms = ms;
-    unsigned long long cnt[4];
+    unsigned long long cnt[6];
     HIP_TRY(hipMemcpy(cnt, h->counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+    if (cnt[5] != 0)
+        return fail(HC_ERR_DEVICE, "split-column kernel: %llu mailbox exchanges timed out (internal error; results are invalid)", cnt[5]);
     // An attempt that exhausts the kernel's iteration budget is abandoned like a solve that gave up (the x0.8
     // retry rule applies); it is counted ([2], last place in [3]) and only fatal on request.
     if (cnt[2] != 0 && h->strict_guard)
