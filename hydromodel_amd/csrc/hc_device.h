@@ -116,6 +116,25 @@ __device__ __forceinline__ void wave_sum2(double &a, double &b)
     a = readlane_d(u, WAVE - 1);
     b = readlane_d(v, WAVE - 1);
 }
+// three sums at once (the fused solve + norm exchange of the split-column kernel)
+__device__ __forceinline__ void wave_sum3(double &a, double &b, double &c)
+{
+    double u = a, v = b, w = c;
+#define HC_SUM3_STEP(CTRL, ...)           \
+    u += dpp_z<CTRL, ##__VA_ARGS__>(u);   \
+    v += dpp_z<CTRL, ##__VA_ARGS__>(v);   \
+    w += dpp_z<CTRL, ##__VA_ARGS__>(w);
+    HC_SUM3_STEP(DPP_QUAD_XOR1)
+    HC_SUM3_STEP(DPP_QUAD_XOR2)
+    HC_SUM3_STEP(DPP_ROW_HALF_MIRROR)
+    HC_SUM3_STEP(DPP_ROW_MIRROR)
+    HC_SUM3_STEP(DPP_ROW_BCAST15, 0xa)
+    HC_SUM3_STEP(DPP_ROW_BCAST31, 0xc)
+#undef HC_SUM3_STEP
+    a = readlane_d(u, WAVE - 1);
+    b = readlane_d(v, WAVE - 1);
+    c = readlane_d(w, WAVE - 1);
+}
 // exclusive prefix sum across lanes (Hillis-Steele inside 16-lane rows, then row broadcasts)
 __device__ __forceinline__ double wave_excl_scan(double v, int lane)
 {
@@ -266,6 +285,9 @@ __device__ __forceinline__ double rsqrt_ge1(double x)
 // per half (release store / acquire load at workgroup scope), no s_barrier (the other pair of the workgroup runs another
 // member with its own control flow).  Both halves execute the same sequence of exchanges: every branch that contains
 // one is decided by values both halves hold identically.
+#ifndef HC_PAIR_SLEEP
+#define HC_PAIR_SLEEP 1
+#endif
 struct PairBox {
     double data[2][2][8];      // [exchange parity][half][value]
     unsigned seq[2];           // exchanges posted by each half
@@ -297,33 +319,48 @@ struct Comm<2> {
     int half;                  // 0: upper half of the column (nodes from 0), 1: lower half
     int lane;
     unsigned k;                // exchanges done so far (identical in both halves)
-    PairBox *box;
-    bool dead;                 // an exchange timed out (a bug, never the data): stop waiting, let the member run out
+    typedef __attribute__((address_space(3))) PairBox LdsBox;     // (a generic pointer would turn every access into a FLAT one)
+    LdsBox *box;
+    int dead;                  // an exchange timed out (a bug, never the data): stop waiting, let the member run out
     unsigned long long *fault; // device counter of such events
     static constexpr int SPIN_LIMIT = 1 << 22;
 
     // Every lane of both waves gets the partner's N values.  `mine` are wave-uniform.
+    // Lane 0 stores payload then sequence number (LDS executes a wave's instructions in order); the reader issues the
+    // sequence load and the payload loads back to back -- one LDS round trip per poll -- and keeps the payload only if the
+    // sequence number it came with is the awaited one (a payload loaded after an up-to-date sequence number is up to date).
     template <int N>
     __device__ __forceinline__ void xchg(const double (&mine)[N], double (&theirs)[N])
     {
         static_assert(N <= 8, "mailbox holds eight values per half");
         const unsigned p = k & 1u;
         if (lane == 0) {
+            volatile __attribute__((address_space(3))) double *out = box->data[p][half];
 #pragma unroll
-            for (int j = 0; j < N; j++) box->data[p][half][j] = mine[j];
-            __hip_atomic_store(&box->seq[half], k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int j = 0; j < N; j++) out[j] = mine[j];
+            *(volatile __attribute__((address_space(3))) unsigned *)&box->seq[half] = k + 1u;
         }
+        const volatile __attribute__((address_space(3))) unsigned *seq = &box->seq[half ^ 1];
+        const volatile __attribute__((address_space(3))) double *in = box->data[p][half ^ 1];
         int spins = 0;
-        while (!dead && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&box->seq[half ^ 1], __ATOMIC_ACQUIRE,
-                                                                              __HIP_MEMORY_SCOPE_WORKGROUP)) < (int)(k + 1u)) {
+        for (;;) {
+            const unsigned got = *seq;
+            double v[N];
+#pragma unroll
+            for (int j = 0; j < N; j++) v[j] = in[j];
+            if ((__builtin_amdgcn_readfirstlane(dead) != 0) | ((int)__builtin_amdgcn_readfirstlane((int)got) >= (int)(k + 1u))) {
+#pragma unroll
+                for (int j = 0; j < N; j++) theirs[j] = uniform_d(v[j]);
+                break;
+            }
+#if HC_PAIR_SLEEP
             __builtin_amdgcn_s_sleep(1);
+#endif
             if (++spins > SPIN_LIMIT) {          // every wave must reach an exit
-                dead = true;
+                dead = 1;
                 if (lane == 0) atomicAdd(fault, 1ull);
             }
         }
-#pragma unroll
-        for (int j = 0; j < N; j++) theirs[j] = uniform_d(box->data[p][half ^ 1][j]);
         k++;
     }
     // upper half's value first: both halves form the same sum, bit for bit

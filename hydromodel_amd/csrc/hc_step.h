@@ -412,7 +412,7 @@ struct TriLU {
     double wf[CPL], wb[CPL], l[CPL], u[CPL], ib[CPL];
     double wx, invB, al[6], ga[6];
     double sp[H == 2 ? CPL : 1];
-    double couple, g_up, g_lo, inv_den;
+    double couple, couple_other, g_up, g_lo, inv_den;
 };
 
 template <int CPL, int H>
@@ -502,11 +502,13 @@ __device__ __forceinline__ void lu_factor(TriLU<CPL, CommT::H> &F, const double 
         lu_solve_block<CPL, H>(F, e, lane);
 #pragma unroll
         for (int c = 0; c < CPL; c++) F.sp[c] = e[c];
-        const double mine[1] = {F.couple * (comm.half == 0 ? readlane_d(e[CPL - 1], WAVE - 1) : readlane_d(e[0], 0))};
-        double theirs[1];
+        const double mine[2] = {F.couple * (comm.half == 0 ? readlane_d(e[CPL - 1], WAVE - 1) : readlane_d(e[0], 0)),
+                                F.couple};
+        double theirs[2];
         comm.xchg(mine, theirs);
         F.g_up = comm.half == 0 ? mine[0] : theirs[0];
         F.g_lo = comm.half == 0 ? theirs[0] : mine[0];
+        F.couple_other = theirs[1];
         F.inv_den = fast_div(1.0, 1.0 - F.g_up * F.g_lo);
     }
 }
@@ -551,6 +553,44 @@ __device__ __forceinline__ void lu_solve(const TriLU<CPL, CommT::H> &F, double (
 #pragma unroll
         for (int c = 0; c < CPL; c++) x[c] = fma(-coef, F.sp[c], x[c]);
     }
+}
+
+// Split column: the Newton solve and the RMS norm of its result in ONE exchange.  With x = z - coef sp in either half,
+//   sum ((x_i / scale_i)^2) = S_zz - 2 coef S_zs + coef^2 S_ss,   S_ab = sum (a_i / scale_i)(b_i / scale_i),
+// so each half sends its block's edge value of z together with its three partial sums; both halves then know both
+// corrections and form the same norm.  (The expansion costs a few digits where z and coef sp nearly cancel; the norm
+// only feeds threshold tests at a 3 % tolerance.)
+template <int CPL>
+__device__ __forceinline__ double lu_solve_norm(const TriLU<CPL, 2> &F, double (&x)[CPL], const double (&is)[CPL],
+                                                int lane, double inv_sqrt_d, Comm<2> &comm)
+{
+    lu_solve_block<CPL, 2>(F, x, lane);
+    double szz = 0.0, szs = 0.0, sss = 0.0;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const double zi = x[c] * is[c], si = F.sp[c] * is[c];
+        szz = fma(zi, zi, szz);
+        szs = fma(zi, si, szs);
+        sss = fma(si, si, sss);
+    }
+    wave_sum3(szz, szs, sss);
+    const double mine[4] = {comm.half == 0 ? readlane_d(x[CPL - 1], WAVE - 1) : readlane_d(x[0], 0), szz, szs, sss};
+    double theirs[4];
+    comm.xchg(mine, theirs);
+    const bool up = comm.half == 0;
+    const double z_up = up ? mine[0] : theirs[0], z_lo = up ? theirs[0] : mine[0];
+    const double x_up = (z_up - F.g_up * z_lo) * F.inv_den;
+    const double x_lo = z_lo - F.g_lo * x_up;
+    const double c_up = (up ? F.couple : F.couple_other) * x_lo;       // the upper half's correction factor
+    const double c_lo = (up ? F.couple_other : F.couple) * x_up;       // the lower half's
+    const double n_up = fma(c_up, fma(c_up, up ? mine[3] : theirs[3], -2.0 * (up ? mine[2] : theirs[2])), up ? mine[1] : theirs[1]);
+    const double n_lo = fma(c_lo, fma(c_lo, up ? theirs[3] : mine[3], -2.0 * (up ? theirs[2] : mine[2])), up ? theirs[1] : mine[1]);
+    const double coef = up ? c_up : c_lo;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) x[c] = fma(-coef, F.sp[c], x[c]);
+    double n2 = n_up + n_lo;
+    n2 = n2 < 0.0 ? 0.0 : n2;                    // (a NaN stays a NaN: the caller's "not finite" test must see it)
+    return sqrt_pos(n2) * inv_sqrt_d;
 }
 
 // _sparse_num_jac bookkeeping for ONE column j: max |f_new - f| over the stored rows j-1, j, j+1
@@ -635,9 +675,9 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         PairBox *boxes = reinterpret_cast<PairBox *>(wave_base + (size_t)WPB * (NVEC_K * SLOTS + WAVE_SCRATCH));
         comm.lane = lane;
         comm.k = 0;
-        comm.dead = false;
+        comm.dead = 0;
         comm.fault = load_const(A.io).counters + 5;
-        comm.box = boxes + (wave >> 1);
+        comm.box = (Comm<2>::LdsBox *)(boxes + (wave >> 1));
         if (lane < 2) comm.box->seq[lane] = 0;       // both halves write the same zeros, before the first exchange of either
         __syncthreads();
     }
@@ -997,9 +1037,14 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #pragma unroll
                             for (int c = 0; c < CPL; c++) dy[c] = cc * f[c] - psiv[c] - dd[c];   // 0 in the padding slots
                             HC_STAMP(20);
-                            lu_solve<CPL>(F, dy, lane, comm);
-                            HC_STAMP(21);
-                            const double dy_norm = rms_ratio<CPL>(dy, scl, lane, D, inv_sqrt_d, comm);
+                            double dy_norm;
+                            if constexpr (HALVES == 2) {
+                                dy_norm = lu_solve_norm<CPL>(F, dy, scl, lane, inv_sqrt_d, comm);
+                            } else {
+                                lu_solve<CPL>(F, dy, lane, comm);
+                                HC_STAMP(21);
+                                dy_norm = rms_ratio<CPL>(dy, scl, lane, D, inv_sqrt_d, comm);
+                            }
                             HC_STAMP(22);
                             // scipy: `if not np.all(np.isfinite(f)): break`.  A non-finite f makes the solve and its
                             // norm non-finite, and the iterate is left untouched either way.

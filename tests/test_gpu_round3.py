@@ -370,3 +370,98 @@ def test_in_library_rccl_allreduce_on_one_gpu(gpu):
         allreduce_handles([st, other])
     other.close()
     st.close()
+
+
+@pytest.mark.parametrize("dim_d", [541, 581, 640])
+def test_split_column_kernel_against_the_one_wave_kernel_and_the_oracle(gpu, dim_d, monkeypatch):
+    """Columns of 513..640 nodes run on TWO cooperating waves per member (DESIGN.md §5 "Split column").  Same inputs
+    through the split-column kernel, through the one-wave kernel of the same depth (HYDROCOL_SPLIT_COLUMN=0) and through
+    the oracle: daylight rows with evapo-transpiration, lateral flow across the cut region, host noise with a refresh
+    row.  The two kernels sum norms and eliminate the tridiagonal system in different orders, so they agree to
+    rounding on the first row (1e-7) and like any two implementations on the chained rows; solver statistics and
+    water-table indices must be the oracle's."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    from oracle.oracle import Oracle
+    params = default_parameters()
+    cols = ColumnTables(params, synthetic_well(dim_d))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+    N, first, rows = 5, 28, 24                         # rows 28..51: daylight until row 35, night, the refresh row 48
+    rng = np.random.default_rng(dim_d)
+    y0 = np.tile(cols.z - 300.0, (N, 1)) + 0.2 * rng.standard_normal((N, cols.dim_d))
+    y0[1] = cols.z - 2400.0                            # a member whose water table lies BELOW the cut (node 320 = 16 m)
+    base = rng.standard_normal((N, cols.dim_d))
+    nf = int(forcing.refresh[first:first + rows].sum())
+    assert nf >= 1
+    fresh = rng.standard_normal((nf, N, cols.dim_d))
+    res = {}
+    for mode in ("split", "one-wave"):
+        if mode == "one-wave":
+            monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")
+        st = gpu.EnsembleStepper(cols, forcing, N)
+        st.set_state(y0)
+        st.set_noise_host(base)
+        out = st.step_rows(first, rows, fresh_noise=fresh, want_wtd=True, want_stats=True, want_psi=True, want_diag=True)
+        res[mode] = out
+        st.close()
+    monkeypatch.delenv("HYDROCOL_SPLIT_COLUMN")
+    a, b = res["split"], res["one-wave"]
+    assert a["kernel_ms"] > 0 and np.isfinite(a["psi"]).all()
+    e = np.max(np.abs(a["psi"] - b["psi"]) / (1 + np.abs(b["psi"])), axis=2)
+    assert e[0].max() < 1e-7, e[0]
+    same_stats = (a["stats"] == b["stats"]).all(axis=2).mean()
+    o = Oracle(cols, forcing.surface_evap)
+    ok = total = 0
+    worst_first = 0.0
+    for k in range(N):
+        r = o.run(forcing, y0[k], base[k], fresh[:, k, :], first, first + rows, want_psi=True, want_stats=True)
+        want = r["psi_rows"][first:first + rows]
+        eo = np.max(np.abs(a["psi"][:, k, :] - want) / (1 + np.abs(want)), axis=1)
+        worst_first = max(worst_first, float(eo[0]))
+        assert eo[0] < 1e-6 and eo.max() < 5e-2, (dim_d, k, eo)
+        ok += int((a["stats"][:, k, :5] == r["per_row"][first:first + rows, :5]).all(axis=1).sum())
+        ok_w = (a["wtd"][:, k] == r["wtd_est"][first:first + rows])
+        assert ok_w.mean() >= 0.9, (dim_d, k)
+        total += rows
+    print(f"[D={dim_d}] split-column vs one-wave kernel: first row {e[0].max():.1e}, all rows {e.max():.1e}, "
+          f"{same_stats:.0%} of the member-rows with identical statistics; vs the oracle: first row {worst_first:.1e}, "
+          f"{ok}/{total} member-rows with the oracle's nfev/njev/nlu/steps/attempts")
+    assert ok >= 0.8 * total
+    # transpiration / lateral-flow diagnostics: the lateral-flow integral is a sum over BOTH halves
+    assert a["diag"][0, :, 0].max() > 0.0 and a["diag"][:, :, 1].max() > 0.0
+    assert np.allclose(a["diag"][0], b["diag"][0], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(a["diag"] - b["diag"])) < 5e-4      # later rows: the water table may cross a cell a row apart
+
+
+def test_deep_columns_fall_back_to_one_wave_where_the_split_kernel_does_not_apply(gpu, monkeypatch):
+    """Several parameter points in one handle (a sweep) keep the one-wave kernels at every depth; so does a column whose
+    root zone reaches into the lower half.  Both still run and agree with stand-alone handles."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import SweepSimulation, check_sweep_points
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    pts = [{"Soil_Properties": {"a0": 0.012}}, {"Soil_Properties": {"n": 2.0}}]
+    cols_all = [ColumnTables(mp, synthetic_well(541)) for mp in check_sweep_points(params, pts)]
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols_all[0])
+    psi0 = np.stack([c.z - 300.0 for c in cols_all])
+    big = SweepSimulation(cols_all, forcing, 6, seed=2, psi0=psi0)
+    big.advance(10)
+    y = big.stepper.get_state()
+    big.close()
+    monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")            # a single point, one-wave kernel forced
+    one = SweepSimulation([cols_all[1]], forcing, 6, seed=2, first_point=1, psi0=psi0[1])
+    one.advance(10)
+    assert np.array_equal(one.stepper.get_state(), y[6:])
+    one.close()
+    monkeypatch.delenv("HYDROCOL_SPLIT_COLUMN")
+    deep_roots = default_parameters()
+    deep_roots["Trees"]["Max_Root_Depth_cm"] = 2000.0           # 400 root-zone cells: beyond the upper half's 320
+    cols = ColumnTables(deep_roots, synthetic_well(581))
+    assert cols.n_root_int > 319
+    forcing = ForcingDigest(deep_roots, synthetic_forcing_frame(1), cols)
+    st = gpu.EnsembleStepper(cols, forcing, 4)
+    st.set_state(cols.z - 300.0)
+    st.set_noise_philox(3, 0)
+    out = st.step_rows(20, 6, want_stats=True)
+    assert np.isfinite(st.get_state()).all() and (out["stats"][:, :, 4] >= 1).all()
+    st.close()

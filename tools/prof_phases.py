@@ -12,10 +12,22 @@ from hydromodel_amd import _lib
 _lib.LIB_PATH = __import__("pathlib").Path(so).resolve()
 from helpers import digest, golden
 from hydromodel_amd.stepper import EnsembleStepper
-_, cols, forcing = digest(300)
-g = golden("g1_tables_300.npz")
+DEPTH = int(os.environ.get("HC_PROF_D", "300"))
+if DEPTH == 300:
+    _, cols, forcing = digest(300)
+    ic = golden("g1_tables_300.npz")["initial_cond"]
+else:       # any depth: synthetic well, spin-up on the GPU (HC_PROF_D=581: the split-column kernel)
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import PHILOX_DRAW_SPINUP, spinup_on_gpu
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    cols = ColumnTables(params, synthetic_well(DEPTH))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+    probe = EnsembleStepper(cols, forcing, 1); probe.set_noise_philox(1, 0)
+    n0 = probe.philox_normals(0, PHILOX_DRAW_SPINUP); probe.close()
+    ic, _, _ = spinup_on_gpu(cols, forcing, n0)
 st = EnsembleStepper(cols, forcing, N)
-st.set_state(g["initial_cond"]); st.set_noise_philox(42, 0)
+st.set_state(ic); st.set_noise_philox(42, 0)
 if row0 > 1:
     st.step_rows(1, row0 - 1)
 prof0 = (C.c_uint64 * 32)(); cnt0 = (C.c_uint64 * 32)()
@@ -56,7 +68,7 @@ print("sub-region entries per column-step: " + ", ".join(f"{SUBS.get(32 + k, 32 
 print(f"RHS evaluations: {cnt[16] / steps:.2f} per column-step, {rhs / max(cnt[16], 1):.0f} cycles each, {100.0 * rhs / tot:.1f} % of the cycles")
 if "--json" in sys.argv:
     path = sys.argv[sys.argv.index("--json") + 1]
-    json.dump({"source": f"{os.path.basename(so)}, {N} members x D=300, rows {row0}..{row0 + 47} (tools/prof_phases.py)",
+    json.dump({"source": f"{os.path.basename(so)}, {N} members x D={DEPTH}, rows {row0}..{row0 + 47} (tools/prof_phases.py)",
                "cycles_per_column_step": {str(k): prof[k] / steps for k in range(32) if prof[k] or cnt[k]},
                "entries_per_column_step": dict({str(k): cnt[k] / steps for k in range(32) if prof[k] or cnt[k]},
                                                **{str(32 + k): sub[k] / steps for k in range(32) if sub[k]})}, open(path, "w"))
