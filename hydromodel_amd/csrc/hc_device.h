@@ -308,6 +308,17 @@ struct Comm<1> {
     __device__ __forceinline__ double up1(double v, int lane, double fill) { return shfl_up1(v, lane, fill); }
     __device__ __forceinline__ double down1(double v, int lane, double fill) { return shfl_down1(v, lane, fill); }
     __device__ __forceinline__ double first_row(double v) { return readlane_d(v, 0); }
+    // N quantities at once: up[j] = previous node's lane of lastc[j], down[j] = next node's lane of firstc[j]
+    template <int N>
+    __device__ __forceinline__ void edges(const double (&lastc)[N], const double (&firstc)[N], const double (&fill)[N],
+                                          int lane, double (&up)[N], double (&down)[N])
+    {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            up[j] = shfl_up1(lastc[j], lane, fill[j]);
+            down[j] = shfl_down1(firstc[j], lane, fill[j]);
+        }
+    }
     __device__ __forceinline__ bool any(bool p) { return __any(p); }
     __device__ __forceinline__ int or_bits(int m) { return m; }
     __device__ __forceinline__ int max_int(int v) { return v; }
@@ -395,6 +406,21 @@ struct Comm<2> {
         double theirs[1];
         xchg(mine, theirs);
         return shfl_down1(v, lane_, half == 0 ? theirs[0] : fill);
+    }
+    template <int N>
+    __device__ __forceinline__ void edges(const double (&lastc)[N], const double (&firstc)[N], const double (&fill)[N],
+                                          int lane_, double (&up)[N], double (&down)[N])
+    {
+        static_assert(N <= 8, "one exchange");
+        double mine[N], theirs[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) mine[j] = half == 0 ? readlane_d(lastc[j], WAVE - 1) : readlane_d(firstc[j], 0);
+        xchg(mine, theirs);
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            up[j] = shfl_up1(lastc[j], lane_, half == 0 ? fill[j] : theirs[j]);
+            down[j] = shfl_down1(firstc[j], lane_, half == 0 ? theirs[j] : fill[j]);
+        }
     }
     __device__ __forceinline__ double first_row(double v)      // node 0's value, in both halves
     {
@@ -1103,7 +1129,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     // split column: the top flux is the lower half's to compute (its last slot holds the top-node cell) and the
     // upper half's to use; the upper half's last cell is the lower half's upper neighbour in the assembly
     double pL_pair = 0.0, edge_C = 0.0, edge_f = 0.0, edge_s = 0.0, edge_ym = 0.0;
-    int jstar_other = -1;
+    int jstar_other = -1, jstar_mine = -1;
     if constexpr (H == 2) {
         const double pl = readlane_d(top_flux(P, R, y_top, kb_top, th_top, pf_top), WAVE - 1);
         bool unsat0[CPL];
@@ -1113,7 +1139,8 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             unsat0[c] = P.flag_lf && (i >= 1) && (i <= D - 2) && !(ym[c] >= P.psi_sat);
         }
         const int j0 = deepest_true<CPL>(unsat0);
-        const double mine[5] = {(double)(j0 < 0 ? -1 : hb + j0), comm.half == 0 ? readlane_d(Cc[CPL - 1], WAVE - 1) : pl,
+        jstar_mine = j0 < 0 ? -1 : hb + j0;
+        const double mine[5] = {(double)jstar_mine, comm.half == 0 ? readlane_d(Cc[CPL - 1], WAVE - 1) : pl,
                                 readlane_d(fl[CPL - 1], WAVE - 1), readlane_d(sk[CPL - 1], WAVE - 1),
                                 readlane_d(ym[CPL - 1], WAVE - 1)};
         double theirs[5];
@@ -1130,16 +1157,17 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     }
     if (P.flag_lf) {
         const int k = D - 2;
-        bool unsat[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const int i = hb + lane * CPL + c;
-            unsat[c] = (i >= 1) && (i <= D - 2) && !(ym[c] >= P.psi_sat);
-        }
-        int jstar = deepest_true<CPL>(unsat);                // midpoint index, local position p = j-1
+        int jstar;                                            // midpoint index, local position p = j-1
         if constexpr (H == 2) {
-            jstar = jstar < 0 ? -1 : hb + jstar;
-            jstar = jstar > jstar_other ? jstar : jstar_other;
+            jstar = jstar_mine > jstar_other ? jstar_mine : jstar_other;     // (found before the exchange above)
+        } else {
+            bool unsat[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int i = hb + lane * CPL + c;
+                unsat[c] = (i >= 1) && (i <= D - 2) && !(ym[c] >= P.psi_sat);
+            }
+            jstar = deepest_true<CPL>(unsat);
         }
         int wtd_est = jstar < 0 ? 0 : jstar;                  // p* + 1
         wtd_est = wtd_est < k - 1 ? wtd_est : k - 1;

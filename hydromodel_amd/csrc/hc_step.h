@@ -1218,10 +1218,21 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         double fb[CPL];
 #pragma unroll
                         for (int c = 0; c < CPL; c++) fb[c] = W.template ld<V_FP>(c * WAVE + lane);
-                        const double fbU0 = comm.up1(fb[CPL - 1], lane, 0.0), fnU0 = comm.up1(ju[CPL - 1], lane, 0.0);
-                        const double fbD0 = comm.down1(fb[0], lane, 0.0), fnD0 = comm.down1(jl[0], lane, 0.0);
-                        const double hU0 = comm.up1(hj[CPL - 1], lane, 1.0), hD0 = comm.down1(hj[0], lane, 1.0);
-                        const double fb_row0 = comm.first_row(fb[0]);
+                        double fbU0, fnU0, fbD0, fnD0, hU0, hD0, fb_row0;
+                        if constexpr (HALVES == 2) {      // the six edge values and row 0's base f in two exchanges
+                            const double lastc[3] = {fb[CPL - 1], ju[CPL - 1], hj[CPL - 1]}, firstc[3] = {fb[0], jl[0], hj[0]};
+                            const double fill[3] = {0.0, 0.0, 1.0};
+                            double up[3], down[3];
+                            comm.edges(lastc, firstc, fill, lane, up, down);
+                            fbU0 = up[0]; fnU0 = up[1]; hU0 = up[2];
+                            fbD0 = down[0]; fnD0 = down[1]; hD0 = down[2];
+                            fb_row0 = comm.first_row(fb[0]);
+                        } else {
+                            fbU0 = comm.up1(fb[CPL - 1], lane, 0.0), fnU0 = comm.up1(ju[CPL - 1], lane, 0.0);
+                            fbD0 = comm.down1(fb[0], lane, 0.0), fnD0 = comm.down1(jl[0], lane, 0.0);
+                            hU0 = comm.up1(hj[CPL - 1], lane, 1.0), hD0 = comm.down1(hj[0], lane, 1.0);
+                            fb_row0 = comm.first_row(fb[0]);
+                        }
                         const int old_flags = jac_stage ? flags_lds[lane] : 0;     // bit c: small, bit 16+c: factor done
                         int small_bits = 0, my_groups = 0;
                         double njl[CPL], njd[CPL], nju[CPL], nfac[CPL];
