@@ -50,6 +50,17 @@ PMC = {
     (300, "special"): {"hbm_bytes_per_member_launch": (2 * 78574.5 + 178688.0) * 1024.0 / 65536.0,
                        "f64_flop_per_column_step": (2019.5 + 3674.7 + 685.3 + 2 * 7846.5) * 64.0,
                        "source": "profiles/r02_pmc_fetch_size.csv, r02_pmc_write_size.csv, r02_pmc_sq_f64_bench.csv"},
+    # generic-exponent kernel step_kernel<5, false, 4, false> (every sweep; n = 1.7 point, 65 536 members, day 1 of the 1-year
+    # forcing): FETCH_SIZE 83 130.3 KiB (calibration launch: 81 252.4 for 153 600 KiB loaded, the x2), WRITE_SIZE 190 243 KiB;
+    # fp64 wave instructions per column-step FMA 14 557 / MUL 5 141 / ADD 3 010 / transcendental 1 001
+    (300, "generic"): {"hbm_bytes_per_member_launch": (2 * 83130.3125 + 190243.0) * 1024.0 / 65536.0,
+                       "f64_flop_per_column_step": (5141.0 + 3010.4 + 1000.9 + 2 * 14557.1) * 64.0,
+                       "source": "profiles/r03_pmc_fetch_generic.csv, r03_pmc_write_generic.csv, r03_pmc_f64_generic.csv"},
+    # BASELINE config 2's kernel step_kernel<4, true, 4, false> (D = 200): FETCH_SIZE 54 457 KiB, WRITE_SIZE 134 149.6 KiB;
+    # FMA 7 091.5 / MUL 3 301.0 / ADD 1 907.7 / transcendental 634.8
+    (200, "special"): {"hbm_bytes_per_member_launch": (2 * 54457.0 + 134149.5625) * 1024.0 / 65536.0,
+                       "f64_flop_per_column_step": (3301.0 + 1907.7 + 634.8 + 2 * 7091.5) * 64.0,
+                       "source": "profiles/r03_pmc_fetch_cpl4.csv, r03_pmc_write_cpl4.csv, r03_pmc_f64_cpl4.csv"},
 }
 
 
@@ -298,6 +309,12 @@ def run_sweep(args, rank, world, dev, dist):
                      "kernel": "hc::step_kernel<5, generic exponents> (rank 0)", "launch_ms": launch_ms,
                      "launches": sim.launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "fp64-VALU/recurrence bound (SURVEY.md §8d); the costliest points set the pace"},
+        "valu_f64": ({"achieved": (col_days / elapsed) * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world,
+                      "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
+                      "frac": (col_days / elapsed) * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world
+                      / FP64_VALU_PEAK_TFLOPS,
+                      "source": "fp64 instruction mix per column-step of the n = 1.7 point from rocprofv3 PMC (profiles/README.md); "
+                                "costlier points do more"} if pmc else None),
         "sweep_rank0": {"spinup_s": spin_s, "spinup_iterations_max": int(np.max(np.abs(sim.spinup_iters))),
                         "spinup_capped": int((np.asarray(sim.spinup_iters) < 0).sum()),
                         "failed_attempts": cnt["failed_attempts"], "guard_trips": cnt["guard_trips"],

@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--asm", default=None, help="use this .s file instead of compiling")
     ap.add_argument("-D", action="append", default=[], help="extra -D for the compile")
     args = ap.parse_args()
-    kernel = args.kernel or f"step_kernelILi{args.cpl}ELb1ELi4ELb0EE"
+    kernel = args.kernel or f"step_kernelILi{args.cpl}ELb1ELi4ELb0ELi1EE"
     path = args.asm or assemble(args.cpl, [f"-D{d}" for d in args.D])
     per = regions_of(path, kernel)
     classes = sorted({c for r in per.values() for c in r})
