@@ -465,3 +465,28 @@ def test_deep_columns_fall_back_to_one_wave_where_the_split_kernel_does_not_appl
     out = st.step_rows(20, 6, want_stats=True)
     assert np.isfinite(st.get_state()).all() and (out["stats"][:, :, 4] >= 1).all()
     st.close()
+
+
+def test_per_member_spinup_on_the_split_column_kernel(gpu, monkeypatch):
+    """`hc_spinup` (every member iterates to its own stop rule inside one launch, simulation.py:389-493) at a depth the
+    split-column kernel serves: the stop rule needs the pair-wide water table and mean squared change; iteration counts
+    must be those of the one-wave kernel and the states agree like two implementations of one contraction."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import spinup_members_on_gpu
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    cols = ColumnTables(params, synthetic_well(581))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+    res = {}
+    for mode in ("split", "one-wave"):
+        if mode == "one-wave":
+            monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")
+        st = gpu.EnsembleStepper(cols, forcing, 5)
+        st.set_noise_philox(13, 100)
+        res[mode] = spinup_members_on_gpu(st, cols, forcing)
+        st.close()
+    monkeypatch.delenv("HYDROCOL_SPLIT_COLUMN")
+    (ya, ia), (yb, ib) = res["split"], res["one-wave"]
+    assert (ia > 0).all() and (ib > 0).all()                      # every member met its stop rule
+    assert np.max(np.abs(ia - ib)) <= 2, (ia, ib)
+    assert np.max(np.abs(ya - yb)) < 0.05                         # cm; the spin-up contracts (DESIGN.md §3)
