@@ -490,3 +490,40 @@ def test_per_member_spinup_on_the_split_column_kernel(gpu, monkeypatch):
     assert (ia > 0).all() and (ib > 0).all()                      # every member met its stop rule
     assert np.max(np.abs(ia - ib)) <= 2, (ia, ib)
     assert np.max(np.abs(ya - yb)) < 0.05                         # cm; the spin-up contracts
+
+
+def test_config3_at_full_size_properties(gpu):
+    """BASELINE configs[2] at its size (262 144 members x D = 300, Philox noise): one simulated day in one launch.  Size-
+    independent properties: every row counts every member, the index sums lie inside the grid, the ensemble has spread
+    (members do differ) -- and any window of members is bit-equal to a small stand-alone handle given the same global
+    ids, i.e. results do not depend on how many members share the launch or the grid."""
+    _, cols, forcing = digest(300)
+    ic = golden("g1_tables_300.npz")["initial_cond"]
+    N, rows = 262144, 48
+    st = gpu.EnsembleStepper(cols, forcing, N)
+    st.set_state(ic)
+    st.set_noise_philox(77, 0)
+    out = st.step_rows(1, rows)
+    assert out["launches"] == 1
+    m = st.moments()
+    assert np.array_equal(m[0, 1:1 + rows], np.full(rows, N))
+    mean_idx = m[1, 1:1 + rows] / N
+    var_idx = m[2, 1:1 + rows] / N - mean_idx ** 2
+    assert (mean_idx > 40).all() and (mean_idx < 80).all() and (var_idx >= 0).all() and var_idx.max() > 0
+    window = st.get_state(200000, 512)
+    tail = st.get_state(N - 3, 3)
+    c = st.counters()
+    st.close()
+    small = gpu.EnsembleStepper(cols, forcing, 512)
+    small.set_state(ic)
+    small.set_noise_philox(77, 200000)
+    small.step_rows(1, rows)
+    assert np.array_equal(small.get_state(), window)
+    small.close()
+    last = gpu.EnsembleStepper(cols, forcing, 3)
+    last.set_state(ic)
+    last.set_noise_philox(77, N - 3)
+    last.step_rows(1, rows)
+    assert np.array_equal(last.get_state(), tail)
+    last.close()
+    assert c["guard_trips"] == 0 and np.isfinite(window).all()
