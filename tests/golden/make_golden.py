@@ -16,6 +16,7 @@ Usage:
     python tests/golden/make_golden.py profiles   # G1 tables for the Constant / Linear / Exponential porosity and the other root pdfs
     python tests/golden/make_golden.py points_short  # first 240 rows of year-long runs at two of those points, ~1 min
     python tests/golden/make_golden.py short      # first days of vanGenuchten / HLIFT / ET+LF-off runs, ~1 min
+    python tests/golden/make_golden.py deep       # G1, G3/G4 and the first 96 rows at the reference's deepest well (no. 14, D = 581)
 
 Vector families:
   G1 static tables / forcing digest     G2 pointwise plugin calls, pressure_head, logN_rnd, find_wtd
@@ -73,8 +74,11 @@ def _wells():
     with open(REF / "model_parameters" / "site_information.json") as fh:
         site = json.load(fh)
     w1 = site["Well"]["1"]
+    w14 = site["Well"]["14"]          # the reference's deepest well: max_depth 2 900 cm -> D = 581 (= synthetic_well(581))
+    deep = {k: w14[k] for k in ("soil", "saprolite", "weathered", "max_depth", "sat_depth")}
+    assert deep == synthetic_well(581), deep
     return {1: {k: w1[k] for k in ("soil", "saprolite", "weathered", "max_depth", "sat_depth")},
-            200: synthetic_well(200), 300: synthetic_well(300)}
+            200: synthetic_well(200), 300: synthetic_well(300), 581: deep}
 
 
 # Non-default parameter points the reference CAN run (n = 2; see DESIGN.md §8 for why n must be an even integer there):
@@ -501,6 +505,13 @@ def main(argv):
         elif mode == "traj":
             well = int(argv[2])
             _save(f"g5_traj_{well}.npz", g5_trajectory(well, tmp))
+        elif mode == "deep":
+            # the reference's deepest well (no. 14, D = 581): tables, RHS, one-row solves and the first two days of its run --
+            # the depth the split-column kernel serves
+            sim, _, _ = _setup(581, tmp)
+            _save("g1_tables_581.npz", g1_tables(sim))
+            _save("g34_states_581.npz", g34_states(sim))
+            _save("g5s_deep_581.npz", g5_short(581, tmp, 96))
         elif mode == "short":
             _save("g5s_vangenuchten_200.npz", g5_short(200, tmp, 480, model="vanGenuchten"))
             _save("g5s_hlift_200.npz", g5_short(200, tmp, 240, flags={"HLIFT": True}))

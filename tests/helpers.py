@@ -9,9 +9,10 @@ from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
-# well 1 of the reference's site_information.json (D = 101) and the two synthetic wells
+# well 1 of the reference's site_information.json (D = 101), the two synthetic wells and the reference's deepest well (D = 581)
 WELLS = {1: {"soil": 0.0, "saprolite": 50.0, "weathered": 200.0, "max_depth": 500.0, "sat_depth": 100.0},
-         200: synthetic_well(200), 300: synthetic_well(300)}
+         200: synthetic_well(200), 300: synthetic_well(300),
+         581: synthetic_well(581)}      # = well 14 of the reference's site_information.json (max_depth 2 900 cm), its deepest
 
 
 @lru_cache(maxsize=None)
