@@ -77,8 +77,10 @@ def _wells():
     w14 = site["Well"]["14"]          # the reference's deepest well: max_depth 2 900 cm -> D = 581 (= synthetic_well(581))
     deep = {k: w14[k] for k in ("soil", "saprolite", "weathered", "max_depth", "sat_depth")}
     assert deep == synthetic_well(581), deep
+    w10 = site["Well"]["10"]          # the well input_parameters.json ships with: max_depth 2 000 cm -> D = 401, sat_depth 125
     return {1: {k: w1[k] for k in ("soil", "saprolite", "weathered", "max_depth", "sat_depth")},
-            200: synthetic_well(200), 300: synthetic_well(300), 581: deep}
+            200: synthetic_well(200), 300: synthetic_well(300), 581: deep,
+            401: {k: w10[k] for k in ("soil", "saprolite", "weathered", "max_depth", "sat_depth")}}
 
 
 # Non-default parameter points the reference CAN run (n = 2; see DESIGN.md §8 for why n must be an even integer there):
@@ -512,6 +514,11 @@ def main(argv):
             _save("g1_tables_581.npz", g1_tables(sim))
             _save("g34_states_581.npz", g34_states(sim))
             _save("g5s_deep_581.npz", g5_short(581, tmp, 96))
+            # ... and the well the reference's input_parameters.json selects (no. 10, D = 401: 7 cells per lane)
+            sim, _, _ = _setup(401, tmp)
+            _save("g1_tables_401.npz", g1_tables(sim))
+            _save("g34_states_401.npz", g34_states(sim))
+            _save("g5s_default_well_401.npz", g5_short(401, tmp, 96))
         elif mode == "short":
             _save("g5s_vangenuchten_200.npz", g5_short(200, tmp, 480, model="vanGenuchten"))
             _save("g5s_hlift_200.npz", g5_short(200, tmp, 240, flags={"HLIFT": True}))

@@ -12,6 +12,8 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 # well 1 of the reference's site_information.json (D = 101), the two synthetic wells and the reference's deepest well (D = 581)
 WELLS = {1: {"soil": 0.0, "saprolite": 50.0, "weathered": 200.0, "max_depth": 500.0, "sat_depth": 100.0},
          200: synthetic_well(200), 300: synthetic_well(300),
+         401: {"soil": 0.0, "saprolite": 50.0, "weathered": 200.0, "max_depth": 2000.0, "sat_depth": 125.0},   # well 10, the
+         # one the reference's input_parameters.json selects
          581: synthetic_well(581)}      # = well 14 of the reference's site_information.json (max_depth 2 900 cm), its deepest
 
 

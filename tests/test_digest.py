@@ -7,7 +7,7 @@ from hydromodel_amd import digest as dg
 from hydromodel_amd.synthetic import default_parameters, synthetic_forcing, synthetic_well
 
 
-@pytest.mark.parametrize("well", [1, 200, 300, 581])
+@pytest.mark.parametrize("well", [1, 200, 300, 401, 581])
 def test_static_tables_match_reference_bit_for_bit(well):
     _, cols, forcing = digest(well)
     g = golden(f"g1_tables_{well}.npz")
@@ -25,7 +25,7 @@ def test_static_tables_match_reference_bit_for_bit(well):
     assert cols.sat_cells == float(g["sat_cells"])
 
 
-@pytest.mark.parametrize("well", [1, 200, 300, 581])
+@pytest.mark.parametrize("well", [1, 200, 300, 401, 581])
 def test_forcing_digest_matches_reference(well):
     _, cols, forcing = digest(well)
     g = golden(f"g1_tables_{well}.npz")

@@ -31,11 +31,12 @@ def forcing_with_row(forcing, row, precip, atm, daylight, wtd_obs):
     return f
 
 
-@pytest.mark.parametrize("well", [1, 200, 300, 581])
+@pytest.mark.parametrize("well", [1, 200, 300, 401, 581])
 def test_every_constructed_state_matches_the_reference_solve(gpu, well):
     """G4 on the GPU directly against the reference: all 13 constructed states the reference
     solved in one attempt (the 14th, HLIFT at night, takes > 1 000 RHS evaluations and is chaotic: the CPU suite skips it
-    too) x 4 wells -- the fourth is the reference's deepest (no. 14, D = 581), which the SPLIT-COLUMN kernel serves --, `RichardsPDE.solve` over t_span (7, 8) (richards_pde.py:478-537) -> forcing row 8 carrying the
+    too) x 5 wells -- among them the well the reference's input_parameters.json selects (no. 10, D = 401, 7 cells per lane)
+    and its deepest (no. 14, D = 581), which the SPLIT-COLUMN kernel serves --, `RichardsPDE.solve` over t_span (7, 8) (richards_pde.py:478-537) -> forcing row 8 carrying the
     state's own (hour, precip, atm, wtd) arguments and flags.  Tiers: a regular row (<= 100 RHS evaluations) must
     reproduce the reference's nfev/njev/nlu/steps and agree to 1e-6 (1 + |psi|); stiff constructed states
     (~200 evaluations, ~75 steps, Jacobian refreshed up to 10 times) decorrelate in the last bits of the FD Jacobian
@@ -529,12 +530,14 @@ def test_config3_at_full_size_properties(gpu):
     assert c["guard_trips"] == 0 and np.isfinite(window).all()
 
 
-def test_first_days_of_the_deepest_reference_well_replay_on_the_split_column_kernel(gpu):
+@pytest.mark.parametrize("well,fname", [(581, "g5s_deep_581.npz"), (401, "g5s_default_well_401.npz")])
+def test_first_days_of_the_deepest_reference_well_replay_on_the_split_column_kernel(gpu, well, fname):
     """96 rows recorded inside the reference's own run at its deepest well (no. 14, max_depth 2 900 cm, D = 581;
     `make_golden.py deep`), each replayed from the reference's input state and noise vector through the split-column
-    kernel: the two-wave layout against the reference itself, not only against the oracle."""
-    _, cols, forcing = digest(581)
-    g = golden("g5s_deep_581.npz")
+    kernel: the two-wave layout against the reference itself, not only against the oracle.  The same for the well the
+    reference's input_parameters.json selects (no. 10, D = 401: the 7-cells-per-lane one-wave kernel)."""
+    _, cols, forcing = digest(well)
+    g = golden(fname)
     st = gpu.EnsembleStepper(cols, forcing, 1)
     errs, same = [], 0
     for k, i in enumerate(g["rows"]):
@@ -550,7 +553,7 @@ def test_first_days_of_the_deepest_reference_well_replay_on_the_split_column_ker
     errs = np.array(errs)
     tiers = {"<1e-9": int((errs < 1e-9).sum()), "1e-9..1e-6": int(((errs >= 1e-9) & (errs < 1e-6)).sum()),
              ">=1e-6 (loose)": int((errs >= 1e-6).sum())}
-    print(f"[well 14, D=581] {len(errs)} reference rows on the split-column kernel: {same} with the reference's "
+    print(f"[D={well}] {len(errs)} reference rows on the {'split-column' if well > 512 else 'one-wave'} kernel: {same} with the reference's "
           f"nfev/njev/nlu/steps/attempts; tiers {tiers}")
     assert same >= 0.9 * len(errs), (same, len(errs))
     assert tiers[">=1e-6 (loose)"] < 0.2 * len(errs), tiers

@@ -14,7 +14,7 @@ from helpers import digest, golden, rel_err
 from oracle.oracle import Oracle, VIEW_FIRST, VIEW_INTERIOR, VIEW_NODES, VIEW_TOP
 
 WELLS = [1, 200, 300]
-DEEP_WELLS = WELLS + [581]          # + the reference's deepest well (fixtures of `make_golden.py deep`)
+DEEP_WELLS = WELLS + [401, 581]     # + the reference's default well (no. 10) and its deepest (no. 14): `make_golden.py deep`
 POINT_TOL = 1e-11
 
 
@@ -228,6 +228,7 @@ def test_rng_stream_plan():
 
 
 SHORT_RUNS = [("g5s_deep_581.npz", 581, "vrettas_fung", 96),      # the reference's deepest well, first two days
+              ("g5s_default_well_401.npz", 401, "vrettas_fung", 96),   # the well input_parameters.json selects
               ("g5s_vangenuchten_200.npz", 200, "vanGenuchten", 480),
               ("g5s_hlift_200.npz", 200, "vrettas_fung", 240),
               ("g5s_noet_nolf_300.npz", 300, "vrettas_fung", 240)]
