@@ -1544,9 +1544,15 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         if (multi && lane == 0) atomicAdd(&io.point_cost[point], (unsigned long long)cost_nfev);
 #ifdef HC_PROFILE
         __builtin_amdgcn_wave_barrier();
-        if (lane < 32) atomicAdd(&io.counters[8 + lane], prof_lds[lane]);
-        if (lane >= 32) atomicAdd(&io.counters[32 + lane], prof_lds[lane]);     // entries: counters[64..95]
-        if (lane < 32) atomicAdd(&io.counters[96 + lane], prof_lds[64 + lane]);  // sub-region entries: counters[96..127]
+        // split column: HC_PROFILE_HALF (default 0) says which half of the pairs reports -- the upper half is the critical path
+#ifndef HC_PROFILE_HALF
+#define HC_PROFILE_HALF 0
+#endif
+        if (HALVES == 1 || comm.half == HC_PROFILE_HALF) {
+            if (lane < 32) atomicAdd(&io.counters[8 + lane], prof_lds[lane]);
+            if (lane >= 32) atomicAdd(&io.counters[32 + lane], prof_lds[lane]);     // entries: counters[64..95]
+            if (lane < 32) atomicAdd(&io.counters[96 + lane], prof_lds[64 + lane]);  // sub-region entries: counters[96..127]
+        }
         prof_lds[lane] = 0;
         if (lane < 32) prof_lds[64 + lane] = 0;
 #endif

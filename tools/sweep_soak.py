@@ -1,6 +1,6 @@
 """BASELINE config 5's full grid on one GPU as a health check: 512 points (8 n x 8 a0 x 8 psi_sat) x M members,
 `days` days in one handle; reports spin-ups, finiteness, failed attempts and iteration-budget trips per point.
-    python tools/sweep_soak.py [M=512] [D=300] [days=30]"""
+    python tools/sweep_soak.py [M=512] [D=300] [days=30] [report_every_days=5]"""
 import json, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
@@ -11,6 +11,7 @@ from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 days = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+report = int(sys.argv[4]) if len(sys.argv) > 4 else 5        # days between health checks / progress lines
 params = default_parameters()
 grid = [(n, a0, ps) for n in np.linspace(1.5, 3.0, 8) for a0 in np.geomspace(0.003, 0.03, 8)
         for ps in -np.geomspace(1e-3, 1.0, 8)]
@@ -27,7 +28,7 @@ print(f"{len(pts)} points x {M} members, D={D}: spin-ups {t_spin:.1f} s, iterati
 done = 0
 cost_prev, ms_prev = sim.stepper.point_costs().astype(float), 0.0
 while done < days:
-    n = min(5, days - done)
+    n = min(report, days - done)
     sim.advance(48 * n)
     done += n
     y = sim.stepper.get_state()
