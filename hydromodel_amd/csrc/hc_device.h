@@ -353,13 +353,17 @@ struct Comm<2> {
         }
         const volatile __attribute__((address_space(3))) unsigned *seq = &box->seq[half ^ 1];
         const volatile __attribute__((address_space(3))) double *in = box->data[p][half ^ 1];
+        // everything that steers the loop is made scalar by hand: the compiler cannot see that k, dead and the polled
+        // sequence number are the same in all lanes, and would otherwise run the loop under exec masks
+        const int want = __builtin_amdgcn_readfirstlane((int)k) + 1;
+        int gone = __builtin_amdgcn_readfirstlane(dead);
         int spins = 0;
         for (;;) {
-            const unsigned got = *seq;
+            const int got = __builtin_amdgcn_readfirstlane((int)*seq);
             double v[N];
 #pragma unroll
             for (int j = 0; j < N; j++) v[j] = in[j];
-            if ((__builtin_amdgcn_readfirstlane(dead) != 0) | ((int)__builtin_amdgcn_readfirstlane((int)got) >= (int)(k + 1u))) {
+            if ((got >= want) | (gone != 0)) {
 #pragma unroll
                 for (int j = 0; j < N; j++) theirs[j] = uniform_d(v[j]);
                 break;
@@ -368,11 +372,12 @@ struct Comm<2> {
             __builtin_amdgcn_s_sleep(1);
 #endif
             if (++spins > SPIN_LIMIT) {          // every wave must reach an exit
-                dead = 1;
+                gone = 1;
                 if (lane == 0) atomicAdd(fault, 1ull);
             }
         }
-        k++;
+        dead = gone;
+        k = (unsigned)want;
     }
     // upper half's value first: both halves form the same sum, bit for bit
     __device__ __forceinline__ double sum(double v)
