@@ -559,3 +559,38 @@ def test_first_days_of_the_deepest_reference_well_replay_on_the_split_column_ker
     assert tiers[">=1e-6 (loose)"] < 0.2 * len(errs), tiers
     assert np.median(errs) < 1e-8 and errs.max() < 5e-2
 
+
+
+def test_config2_at_full_size_whole_year(gpu):
+    """BASELINE configs[1] at its size: 4 096 members x D = 200 through the WHOLE 1-year forcing (17 519 rows).  Properties
+    that do not depend on the size: every solved row counts every member; the per-row moments do not depend on how the
+    year is cut into launches (the library's choice for this ensemble -- 16 days per launch -- against 5-day launches);
+    the first members equal a small stand-alone handle; states stay finite and the water table stays on the grid."""
+    _, cols, forcing = digest(200)
+    ic = golden("g1_tables_200.npz")["initial_cond"]
+    N, T = 4096, forcing.dim_t
+    res = []
+    for rows_per_launch in (0, 240):
+        st = gpu.EnsembleStepper(cols, forcing, N)
+        if rows_per_launch:
+            st.set_rows_per_launch(rows_per_launch)
+        st.set_state(ic)
+        st.set_noise_philox(2, 0)
+        out = st.step_rows(1, T - 1)
+        res.append((st.moments(), st.get_state(0, 8), st.counters(), out["launches"]))
+        st.close()
+    (m, y, c, l0), (m2, y2, c2, l1) = res
+    assert l0 < l1 and l1 == -(-(T - 1) // 240)
+    assert np.array_equal(m, m2) and np.array_equal(y, y2) and c["failed_attempts"] == c2["failed_attempts"]
+    assert np.array_equal(m[0, 1:], np.full(T - 1, N))
+    mean_idx = m[1, 1:] / N
+    assert np.isfinite(y).all() and mean_idx.min() > 30 and mean_idx.max() < 120
+    small = gpu.EnsembleStepper(cols, forcing, 8)
+    small.set_state(ic)
+    small.set_noise_philox(2, 0)
+    small.step_rows(1, T - 1)
+    assert np.array_equal(small.get_state(), y)
+    small.close()
+    print(f"config 2 at full size: {N} members x D=200 x {T - 1} rows; failed attempts {c['failed_attempts']} "
+          f"({c['failed_attempts'] / N:.2f} per member-year), budget trips {c['guard_trips']}; water-table index mean "
+          f"{mean_idx.min():.1f}..{mean_idx.max():.1f}")
