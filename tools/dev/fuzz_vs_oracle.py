@@ -1,0 +1,121 @@
+"""Random configurations through the GPU stepper and the CPU oracle: depth (incl. the lane-boundary and split-column
+edges), plugin, exponents, flags (ET / LF / HLIFT / repaired PREDICT), root depth, water-table observation, launch
+partition.  Each case: 3 members, `rows` chained rows from a hydrostatic-like state with host noise.
+    python tools/dev/fuzz_vs_oracle.py [n_cases=40] [seed=1] [rows=20]
+Prints one line per case (chained errors for information, the row-by-row replay as the verdict) and a summary; exit
+status 1 if a case leaves the tolerance tiers of DESIGN.md §3."""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R)
+import numpy as np
+from hydromodel_amd.digest import ColumnTables, ForcingDigest
+from hydromodel_amd.stepper import EnsembleStepper
+from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+from oracle.oracle import Oracle
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rows = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+rng = np.random.default_rng(seed)
+frame = synthetic_forcing_frame(1)
+EDGES = [64, 65, 127, 128, 129, 192, 193, 256, 257, 319, 320, 321, 384, 385, 448, 449, 511, 512, 513, 514, 576, 577, 639, 640]
+bad = 0
+t00 = time.time()
+for case in range(n_cases):
+    D = int(rng.choice(EDGES)) if rng.random() < 0.5 else int(rng.integers(40, 641))
+    params = default_parameters()
+    model = "vanGenuchten" if rng.random() < 0.25 else "vrettas_fung"
+    params["Hydrological_Model"]["Name"] = model
+    if rng.random() < 0.4:
+        params["Soil_Properties"]["n"] = float(rng.choice([1.5, 1.8, 2.0, 2.4, 3.0]))
+        params["Hydraulic_Conductivity"]["Lambda_Exponent"] = float(rng.choice([1.0, 0.8, 1.3]))
+    flags = {"ET": bool(rng.random() < 0.8), "LF": bool(rng.random() < 0.8), "HLIFT": bool(rng.random() < 0.15),
+             "PREDICT": bool(rng.random() < 0.15)}
+    params["Simulation_Flags"].update(flags)
+    params["Trees"]["Max_Root_Depth_cm"] = float(rng.choice([300.0, 1000.0, 1000.0, 1595.0, 1600.0, 2000.0]))
+    well = synthetic_well(D)
+    well["sat_depth"] = float(rng.choice([100.0, 5.0, 400.0]))
+    wtd_m = float(rng.choice([-3.0, -1.0, -8.0, -17.0]))
+    if abs(wtd_m) * 100.0 > well["max_depth"] - 10.0:
+        wtd_m = -min(3.0, (well["max_depth"] - 20.0) / 100.0)
+    fr = frame.copy()
+    fr["WTD_m"] = wtd_m
+    try:
+        cols = ColumnTables(params, well)
+        forcing = ForcingDigest(params, fr, cols)
+    except Exception as e:  # noqa: BLE001 -- a configuration the digest refuses is not a kernel case
+        print(f"case {case}: D={D} skipped by the digest ({e})")
+        continue
+    N = 3
+    table = abs(wtd_m) * 100.0
+    y0 = np.tile(cols.z - table, (N, 1)) + 0.3 * rng.standard_normal((N, D))
+    base = rng.standard_normal((N, D))
+    first = int(rng.choice([1, 14, 30, 40]))
+    nf = int(forcing.refresh[first:first + rows].sum())
+    fresh = rng.standard_normal((nf, N, D))
+    st = EnsembleStepper(cols, forcing, N)
+    if rng.random() < 0.3:
+        st.set_rows_per_launch(int(rng.choice([1, 3, 7])))
+    st.set_state(y0)
+    st.set_noise_host(base)
+    out = st.step_rows(first, rows, fresh_noise=fresh, want_wtd=True, want_stats=True, want_psi=True)
+    guard = st.counters()["guard_trips"]
+    st.close()
+    o = Oracle(cols, forcing.surface_evap)
+    worst_first = worst = 0.0
+    same = wsame = 0
+    for k in range(N):
+        r = o.run(forcing, y0[k], base[k], fresh[:, k, :], first, first + rows, want_psi=True, want_stats=True)
+        want = r["psi_rows"][first:first + rows]
+        e = np.max(np.abs(out["psi"][:, k, :] - want) / (1 + np.abs(want)), axis=1)
+        worst_first, worst = max(worst_first, e[0]), max(worst, e.max())
+        same += int((out["stats"][:, k, :5] == r["per_row"][first:first + rows, :5]).all(axis=1).sum())
+        wsame += int((out["wtd"][:, k] == r["wtd_est"][first:first + rows]).sum())
+    tot = N * rows
+    # The verdict: member 0 row by row FROM THE ORACLE'S OWN STATES (chained trajectories of two implementations part
+    # ways on stiff rows -- hydraulic lift at night, the discontinuous PREDICT sink, steep exponents -- however right
+    # each row is): the RHS must agree everywhere, regular rows (<= 100 oracle evaluations) must reproduce the oracle's
+    # statistics and state, stiff rows stay within the integrator's accuracy class.
+    r0 = o.run(forcing, y0[0], base[0], fresh[:, 0, :], first, first + rows, want_psi=True, want_stats=True)
+    states = np.vstack([y0[0][None, :], r0["psi_rows"][first:first + rows]])
+    retried = np.flatnonzero(r0["per_row"][first:first + rows, 4] > 1)
+    n_ok = int(retried[0]) if retried.size else rows          # after a retry the oracle's damped base vector is not tracked here
+    st1 = EnsembleStepper(cols, forcing, 1)
+    rhs_worst = reg_worst = stiff_worst = 0.0
+    reg_rows = reg_same = seen = 0
+    for k in range(n_ok):
+        row = first + k
+        refresh = bool(forcing.refresh[row])
+        st1.set_state(states[k][None, :])
+        st1.set_noise_host(base[:1])
+        if not refresh:
+            ref = o.rhs(Oracle.row(forcing.precip[row], forcing.atm[row], forcing.daylight[row], forcing.wtd_obs[row],
+                                   wet=int(forcing.wet_season[row])), states[k], base[0])
+            got = st1.rhs(row)[0]
+            rhs_worst = max(rhs_worst, float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))))
+        fz = fresh[seen, 0][None, None, :] if refresh else np.zeros((0,))
+        o1 = st1.step_rows(row, 1, fresh_noise=fz, want_stats=True)
+        seen += int(refresh)
+        e1 = float(np.max(np.abs(st1.get_state()[0] - states[k + 1]) / (1 + np.abs(states[k + 1]))))
+        if r0["per_row"][row, 0] <= 100:
+            reg_rows += 1
+            reg_same += o1["stats"][0, 0, :5].tolist() == r0["per_row"][row, :5].tolist()
+            reg_worst = max(reg_worst, e1)
+        else:
+            stiff_worst = max(stiff_worst, e1)
+    st1.close()
+    # tiers: the default exponents of vrettas_fung are the tight class; generic exponents / vanGenuchten (powers through
+    # exp-log against libm pow, cancellation near saturation), the PREDICT sink (discontinuous) and hydraulic lift
+    # (flux terms ~1e3 divided by C ~ 1e-7: the RHS itself is ill-conditioned) are held to the integrator's own class
+    plain = (model == "vrettas_fung" and params["Soil_Properties"]["n"] == 2.0
+             and params["Hydraulic_Conductivity"]["Lambda_Exponent"] == 1.0 and not flags["HLIFT"] and not flags["PREDICT"])
+    ok = bool(np.isfinite(out["psi"]).all() and rhs_worst < (1e-5 if flags["HLIFT"] else 1e-7)
+              and reg_worst < (1e-5 if plain else 2e-3) and (stiff_worst < 0.5 or flags["HLIFT"] or guard > 0)
+              and reg_same >= 0.9 * reg_rows)
+    bad += not ok
+    print(f"case {case}: D={D} {model} n={params['Soil_Properties']['n']} lam={params['Hydraulic_Conductivity']['Lambda_Exponent']} "
+          f"{''.join(k[0] if v else '-' for k, v in flags.items())} roots={params['Trees']['Max_Root_Depth_cm']:.0f} sat={well['sat_depth']:.0f} "
+          f"wtd={wtd_m} rows {first}+{rows}: first row {worst_first:.1e}, all rows {worst:.1e}, statistics {same}/{tot}, wtd {wsame}/{tot}, "
+          f"budget trips {guard}; row by row: RHS {rhs_worst:.1e}, regular rows {reg_worst:.1e} ({reg_same}/{reg_rows} statistics), "
+          f"stiff rows {stiff_worst:.1e} {'ok' if ok else 'OUT OF TIER'}", flush=True)
+print(f"{n_cases} cases, {bad} out of tier, {time.time() - t00:.0f} s")
+sys.exit(1 if bad else 0)
