@@ -26,6 +26,87 @@ hipError_t step_pair_one(const LaunchCfg &cfg, const StepArgs &A)
 }
 }  // namespace
 
+// RHS hook on the split-column path: two waves per member, the same rhs_eval<..., Comm<2>> the step kernel inlines
+template <bool SPECIAL, bool PREDICT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK *WAVE, 1) void rhs_pair_kernel(const StepArgs A, long long row, double *dydt)
+{
+    constexpr int CPL = PAIR_CPL, SLOTS = WAVE * CPL, TSLOTS = 2 * SLOTS, WPB = WAVES_PER_BLOCK;
+    extern __shared__ double lds[];
+    double *tab = lds;
+    PairBox *boxes = reinterpret_cast<PairBox *>(tab + NTAB * TSLOTS);
+    for (int k = threadIdx.x; k < NTAB * TSLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
+    if (threadIdx.x < 2 * (WPB / 2)) boxes[threadIdx.x >> 1].seq[threadIdx.x & 1] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const long long member = (long long)blockIdx.x * (WPB / 2) + (wave >> 1);
+    if (member >= A.n_members) return;                     // (both waves of the pair leave together)
+    const ColumnDev P = load_const(A.P);
+    const IoArgs io = load_const(A.io);
+    const int D = P.D;
+    Comm<2> comm;
+    comm.half = wave & 1;
+    comm.lane = lane;
+    comm.k = 0;
+    comm.dead = 0;
+    comm.fault = io.counters + 5;
+    comm.box = (Comm<2>::LdsBox *)(boxes + (wave >> 1));
+    const int hb = comm.half * SLOTS;
+    RowDev R;
+    R.precip = io.precip[row];
+    R.atm = io.atm[row];
+    R.daylight = io.daylight[row] & 1;
+    R.wet = (io.daylight[row] >> 1) & 1;
+    R.wtd_obs = io.wtd_obs[row];
+    R.spinup = A.spinup;
+    R.diag = 0;
+    double y[CPL], rnd[CPL], f[CPL];
+    double dtr = 0.0, dlf = 0.0;
+#ifdef HC_PROFILE
+    unsigned long long prof_dummy[96], prof_t = 0;
+    unsigned long long *prof_lds = prof_dummy;
+    int prof_slot = 0;
+#endif
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = hb + lane * CPL + c;
+        y[c] = i < D ? io.psi[member * D + i] : 0.0;
+        int idx = i >= 1 ? i - 1 : 0;                       // cell i reads n_rnd[max(i - 1, 0)]; the top-node cell n_rnd[0]
+        idx = (i < D - 1) ? idx : 0;
+        double z;
+        if (A.host_noise)
+            z = io.base_noise[member * D + idx];
+        else
+            z = philox_normal(io.seed, (unsigned long long)(io.member_offset + member), 0u, (unsigned)idx) * io.nscale[member];
+        rnd[c] = tab[T_NOISEC * TSLOTS + hb + c * WAVE + lane] * z;
+    }
+    rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tab + hb, lane, y, rnd, f, nullptr, dtr, dlf, comm HC_RHS_PROF_ARG);
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int i = hb + lane * CPL + c;
+        if (i < D) dydt[member * D + i] = f[c];
+    }
+}
+
+namespace {
+template <bool SPECIAL, bool PREDICT>
+hipError_t rhs_pair_one(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt)
+{
+    auto kern = rhs_pair_kernel<SPECIAL, PREDICT>;
+    const size_t lds = (size_t)NTAB * 2 * WAVE * PAIR_CPL * 8 + (WAVES_PER_BLOCK / 2) * sizeof(PairBox);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(WAVES_PER_BLOCK * WAVE), lds, cfg.stream, A, row, dydt);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_rhs_pair(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt)
+{
+    if (cfg.special) return cfg.predict ? rhs_pair_one<true, true>(cfg, A, row, dydt) : rhs_pair_one<true, false>(cfg, A, row, dydt);
+    return cfg.predict ? rhs_pair_one<false, true>(cfg, A, row, dydt) : rhs_pair_one<false, false>(cfg, A, row, dydt);
+}
+
 hipError_t launch_step_pair(const LaunchCfg &cfg, const StepArgs &A)
 {
     if (cfg.special) return cfg.predict ? step_pair_one<true, true>(cfg, A) : step_pair_one<true, false>(cfg, A);

@@ -42,6 +42,7 @@ template <int CPL> hipError_t launch_rhs_cpl(const LaunchCfg &cfg, const StepArg
 // -DHC_INST_PAIR)
 constexpr int PAIR_CPL = 5;
 hipError_t launch_step_pair(const LaunchCfg &cfg, const StepArgs &A);
+hipError_t launch_rhs_pair(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt);   // test hook, no aux
 #define HC_DECLARE_CPL(N)                                                                    \
     template <> hipError_t launch_step_cpl<N>(const LaunchCfg &cfg, const StepArgs &A);       \
     template <> hipError_t launch_rhs_cpl<N>(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt, \

@@ -377,6 +377,14 @@ int launch_step(hc_handle *h, const StepArgs &A)
 int launch_rhs(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
 {
     const int wpb = wpb_of(h->cpl);
+    if (h->use_pair() && !aux) {          // the split-column code path (the c | s | f view stays with the one-wave hook)
+        StepArgs B = A;
+        B.tab = h->tab_pair.p;
+        B.gtab = h->gtab_pair.p;
+        const unsigned grid = (unsigned)((A.n_members + wpb / 2 - 1) / (wpb / 2));
+        HIP_TRY(launch_rhs_pair(launch_cfg(h, grid), B, row, dydt));
+        return HC_OK;
+    }
     const unsigned grid = (unsigned)((A.n_members + wpb - 1) / wpb);
     bool known = false;
     const hipError_t err = launch_rhs_cpl_any(h->cpl, known, launch_cfg(h, grid), A, row, dydt, aux);

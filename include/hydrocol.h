@@ -227,7 +227,8 @@ int hc_get_point_costs(hc_handle *h, uint64_t *cost);
 
 /* Test hooks -------------------------------------------------------------------------- */
 /* dydt for every member's current state on forcing row `row` (noise = base vectors).
- * aux (nullable): [n_members][3*(D-1)+1] = c | s | f at the midpoints, then pL. */
+ * aux (nullable): [n_members][3*(D-1)+1] = c | s | f at the midpoints, then pL.  Columns the split-column kernel serves
+ * are evaluated on that path (two wavefronts per member) when aux is NULL, on the one-wave path when it is requested. */
 int hc_rhs(hc_handle *h, int64_t row, int32_t spinup, double *dydt, double *aux);
 /* plugin call on the nodes for every member's current state: out [4][n_members][D]
  * = theta, K, C, K_bkg; qinf [n_members] (nullable) */

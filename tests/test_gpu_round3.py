@@ -594,3 +594,34 @@ def test_config2_at_full_size_whole_year(gpu):
     print(f"config 2 at full size: {N} members x D=200 x {T - 1} rows; failed attempts {c['failed_attempts']} "
           f"({c['failed_attempts'] / N:.2f} per member-year), budget trips {c['guard_trips']}; water-table index mean "
           f"{mean_idx.min():.1f}..{mean_idx.max():.1f}")
+
+
+@pytest.mark.parametrize("mode", ["split", "one-wave"])
+def test_rhs_at_the_deepest_reference_well_matches_the_reference(gpu, mode, monkeypatch):
+    """G3 at the reference's deepest well (no. 14, D = 581): dy/dt of all 14 constructed states -- night / day, rain, capped
+    infiltration, saturated top, lateral flow, spin-up flag, HYDRAULIC LIFT, ET off, LF off -- straight from
+    `RichardsPDE.__call__`, through the RHS hook on the split-column path (two waves per member: edge states, water-table
+    search, top flux and the cut's cell all cross the mailbox) and through the one-wave kernel of the same depth."""
+    from helpers import rel_err
+    if mode == "one-wave":
+        monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")
+    _, cols, forcing = digest(581)
+    g = golden("g34_states_581.npz")
+    worst = 0.0
+    for name in g["names"]:
+        name = str(name)
+        fl = g[f"{name}_flags"]
+        hour = int(g[f"{name}_hour"])
+        f8 = forcing_with_row(forcing, 8, float(g[f"{name}_precip"]), float(g[f"{name}_atm"]), 6 <= hour <= 17,
+                              int(g["wtd_idx"]))
+        st = gpu.EnsembleStepper(cols, f8, 2, flags={"ET": bool(fl[1]), "LF": bool(fl[2]), "HLIFT": bool(fl[3])})
+        st.set_state(np.tile(g[f"{name}_y"], (2, 1)))
+        st.set_noise_host(np.tile(g["n_rnd"], (2, 1)))
+        dydt = st.rhs(8, spinup=bool(fl[0]))
+        st.close()
+        assert np.array_equal(dydt[0], dydt[1])
+        e = rel_err(dydt[0], g[f"{name}_dydt"])          # relative to max(1, |ref|) element by element
+        worst = max(worst, e)
+        # hydraulic lift adds flux terms ~1e3 that cancel to ~1e-2 before the division by C ~ 1e-7
+        assert e < (1e-4 if fl[3] else 1e-7), (mode, name, e)
+    print(f"[{mode}] RHS of 14 constructed states at D = 581 vs the reference: worst {worst:.1e}")
