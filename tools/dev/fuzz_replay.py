@@ -42,7 +42,6 @@ for k in range(rows):
     y1 = st.get_state()[0]
     e = np.max(np.abs(y1 - states[k + 1]) / (1 + np.abs(states[k + 1])))
     # RHS at the row's start state
-    dg = st.rhs(row)[0] if D <= 512 or True else None
     st.set_state(states[k][None, :])
     dydt_gpu = st.rhs(row)[0]
     dydt_o = o.rhs(Oracle.row(forcing.precip[row], forcing.atm[row], forcing.daylight[row], forcing.wtd_obs[row], wet=int(forcing.wet_season[row])), states[k], fresh[seen - 1] if refresh else base)
