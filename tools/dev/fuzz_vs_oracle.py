@@ -1,7 +1,7 @@
 """Random configurations through the GPU stepper and the CPU oracle: depth (incl. the lane-boundary and split-column
 edges), plugin, exponents, flags (ET / LF / HLIFT / repaired PREDICT), root depth, water-table observation, launch
 partition.  Each case: 3 members, `rows` chained rows from a hydrostatic-like state with host noise.
-    python tools/dev/fuzz_vs_oracle.py [n_cases=40] [seed=1] [rows=20]
+    python tools/dev/fuzz_vs_oracle.py [n_cases=40] [seed=1] [rows=20] [--deep]
 Prints one line per case (chained errors for information, the row-by-row replay as the verdict) and a summary; exit
 status 1 if a case leaves the tolerance tiers of DESIGN.md §3."""
 import os, sys, time
@@ -15,6 +15,7 @@ from oracle.oracle import Oracle
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+DEEP_ONLY = "--deep" in sys.argv                           # depths 513 .. 640 only, water tables around and below the cut too
 rng = np.random.default_rng(seed)
 frame = synthetic_forcing_frame(1)
 EDGES = [64, 65, 127, 128, 129, 192, 193, 256, 257, 319, 320, 321, 384, 385, 448, 449, 511, 512, 513, 514, 576, 577, 639, 640]
@@ -22,6 +23,8 @@ bad = 0
 t00 = time.time()
 for case in range(n_cases):
     D = int(rng.choice(EDGES)) if rng.random() < 0.5 else int(rng.integers(40, 641))
+    if DEEP_ONLY:                                          # the split-column kernel's range
+        D = int(rng.choice([513, 514, 541, 576, 577, 581, 639, 640])) if rng.random() < 0.5 else int(rng.integers(513, 641))
     params = default_parameters()
     model = "vanGenuchten" if rng.random() < 0.25 else "vrettas_fung"
     params["Hydrological_Model"]["Name"] = model
@@ -34,7 +37,7 @@ for case in range(n_cases):
     params["Trees"]["Max_Root_Depth_cm"] = float(rng.choice([300.0, 1000.0, 1000.0, 1595.0, 1600.0, 2000.0]))
     well = synthetic_well(D)
     well["sat_depth"] = float(rng.choice([100.0, 5.0, 400.0]))
-    wtd_m = float(rng.choice([-3.0, -1.0, -8.0, -17.0]))
+    wtd_m = float(rng.choice([-3.0, -1.0, -8.0, -17.0] + ([-15.9, -16.0, -16.1, -22.0, -27.0] if DEEP_ONLY else [])))
     if abs(wtd_m) * 100.0 > well["max_depth"] - 10.0:
         wtd_m = -min(3.0, (well["max_depth"] - 20.0) / 100.0)
     fr = frame.copy()
