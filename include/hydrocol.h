@@ -27,6 +27,12 @@
  *                         point of a parameter sweep, all points stepped by ONE launch
  *   hc_plugin_eval     <- HydrologicalModel subclasses called directly: VrettasFung.__call__(psi, z, {"n_rnd": ..})
  *                         (src/models/vrettas_fung.py:51-257), vanGenuchten.__call__ (src/models/vanGenuchten.py:23-126)
+ *   hc_get/set_noise_scale <- the in-place damping `args["n_rnd"] *= 0.8` of a failed attempt (src/richards_pde.py:522) as
+ *                         it accumulates on a member's base vector; with hc_get_state / hc_get_moments the restart state
+ *                         of an ensemble (the reference restarts one column from IC_Filename, src/simulation.py:358-385)
+ *   hc_set_point_member_bases <- which realisation a member is: the reference seeds one generator per run
+ *                         (src/simulation.py:66-70); here member j of sweep point k draws stream base[k] + j
+ *   hc_allreduce_moments, hc_get_point_costs <- (new) the ensemble's one collective; per-point cost for scheduling
  *
  * Conventions: every function returns 0 on success or a negative hc_status; nothing throws
  * or aborts across the boundary; hc_last_error() gives the thread-local message.  Host
