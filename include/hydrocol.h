@@ -99,7 +99,9 @@ int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_ta
  * drops any further points; hc_add_point appends one more point with tables of its own (same dim_d, n_groups, dz).
  * With P points the n_members of hc_set_members must be a multiple of P and are point-major: point k owns members
  * [k * n_members / P, (k + 1) * n_members / P).  One hc_step_rows / hc_spinup launch advances every point; each
- * member sees the column parameters and tables of its own point; moments are kept per point. */
+ * member sees the column parameters and tables of its own point; moments are kept per point.  Adding a point changes
+ * the shape of the moment table ([n_points][3][T]): whatever was accumulated before is dropped (the table is re-created,
+ * zeroed, by the next call that needs it) -- install all points before the first hc_step_rows. */
 int hc_add_point(hc_handle *h, const hc_column_params *p, const double *node_tabs, const double *mid_tabs);
 int hc_get_point_count(hc_handle *h); /* >= 1 once hc_set_column has run; negative on error */
 /* The cell model comes in two builds: one specialised for the reference's default exponents (vrettas_fung, n = 2,
