@@ -15,7 +15,7 @@ namespace {
 template <bool SPECIAL, bool PREDICT>
 hipError_t step_pair_one(const LaunchCfg &cfg, const StepArgs &A)
 {
-    constexpr int WPB = wpb_of(PAIR_CPL);
+    constexpr int WPB = wpb_of(PAIR_CPL, 2);
     auto kern = step_kernel<PAIR_CPL, SPECIAL, WPB, PREDICT, 2>;
     const size_t lds = step_lds_bytes(PAIR_CPL, WPB, 2);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -28,9 +28,9 @@ hipError_t step_pair_one(const LaunchCfg &cfg, const StepArgs &A)
 
 // RHS hook on the split-column path: two waves per member, the same rhs_eval<..., Comm<2>> the step kernel inlines
 template <bool SPECIAL, bool PREDICT>
-__global__ __launch_bounds__(WAVES_PER_BLOCK *WAVE, 1) void rhs_pair_kernel(const StepArgs A, long long row, double *dydt)
+__global__ __launch_bounds__(wpb_of(PAIR_CPL, 2) * WAVE, 1) void rhs_pair_kernel(const StepArgs A, long long row, double *dydt)
 {
-    constexpr int CPL = PAIR_CPL, SLOTS = WAVE * CPL, TSLOTS = 2 * SLOTS, WPB = WAVES_PER_BLOCK;
+    constexpr int CPL = PAIR_CPL, SLOTS = WAVE * CPL, TSLOTS = 2 * SLOTS, WPB = wpb_of(PAIR_CPL, 2);
     extern __shared__ double lds[];
     double *tab = lds;
     PairBox *boxes = reinterpret_cast<PairBox *>(tab + NTAB * TSLOTS);
@@ -92,11 +92,12 @@ template <bool SPECIAL, bool PREDICT>
 hipError_t rhs_pair_one(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt)
 {
     auto kern = rhs_pair_kernel<SPECIAL, PREDICT>;
-    const size_t lds = (size_t)NTAB * 2 * WAVE * PAIR_CPL * 8 + (WAVES_PER_BLOCK / 2) * sizeof(PairBox);
+    constexpr int WPB = wpb_of(PAIR_CPL, 2);
+    const size_t lds = (size_t)NTAB * 2 * WAVE * PAIR_CPL * 8 + (WPB / 2) * sizeof(PairBox);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(WAVES_PER_BLOCK * WAVE), lds, cfg.stream, A, row, dydt);
+    hipLaunchKernelGGL(kern, dim3(cfg.grid), dim3(WPB * WAVE), lds, cfg.stream, A, row, dydt);
     return hipGetLastError();
 }
 }  // namespace

@@ -18,9 +18,6 @@ struct LaunchCfg {
     bool predict;        // repaired PREDICT lateral flow compiled in
 };
 
-// four waves per workgroup (one per SIMD) at every depth: what does not fit in LDS lives in StepArgs::wave_spill
-constexpr int wpb_of(int) { return WAVES_PER_BLOCK; }
-
 inline size_t step_lds_bytes(int cpl, int wpb, int halves = 1)
 {
     const size_t slots = (size_t)WAVE * cpl;

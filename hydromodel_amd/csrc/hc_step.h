@@ -70,15 +70,22 @@ constexpr int WAVE_SCRATCH = 256;   // + per wave: 32 cycle sums, 32 entry count
 #else
 constexpr int WAVE_SCRATCH = 160;
 #endif
-#ifndef HC_WAVES_PER_BLOCK
-#define HC_WAVES_PER_BLOCK 4
+// Waves per workgroup = per CU (LDS admits one workgroup): one wave per SIMD, except the shallow columns.  At two or
+// three cells per lane the step kernel wants ~350 / ~400 registers; held to 256 (two waves per SIMD) it spills ~100 /
+// ~150 of them to scratch and still gains +48 % / +12 % (D <= 128 / <= 192, r03 measurement in DESIGN.md §5) because a
+// second wave fills the dependency stalls of the first.  From four cells per lane on the spill traffic outweighs that
+// (D = 256: 0.63x, D = 300: 0.59x), and three or four waves per SIMD lose at every depth (D = 128: 0.64x / 0.48x).
+// -DHC_WAVES_PER_BLOCK=n forces one count everywhere (A/B builds).
+#ifdef HC_WAVES_PER_BLOCK
+__host__ __device__ constexpr int wpb_of(int, int = 1) { return HC_WAVES_PER_BLOCK; }
+constexpr int MAX_WAVES_PER_BLOCK = HC_WAVES_PER_BLOCK;
+#else
+__host__ __device__ constexpr int wpb_of(int cpl, int halves = 1) { return (halves == 1 && cpl <= 3) ? 8 : 4; }
+constexpr int MAX_WAVES_PER_BLOCK = 8;
 #endif
-// One wave per SIMD at every column depth.  (-DHC_WAVES_PER_BLOCK=8 is the two-waves-per-SIMD experiment of DESIGN.md §5:
-// the compiler is held to 256 registers per wave and half of the per-wave vectors move to the global region.)
-constexpr int WAVES_PER_BLOCK = HC_WAVES_PER_BLOCK;
 constexpr int LDS_BYTES = 160 * 1024;
-// Where they live.  Up to CPL = 5 (D <= 320) all twelve fit in LDS next to the shared tables with four waves per
-// workgroup.  Deeper columns keep four waves per CU -- every SIMD busy -- by moving the vectors that are touched least
+// Where they live.  At CPL = 4 and 5 (D <= 320) all twelve fit in LDS next to the shared tables with four waves per
+// workgroup (at CPL = 3 with eight waves, eleven do).  Deeper columns keep four waves per CU -- every SIMD busy -- by moving the vectors that are touched least
 // to a per-wave region in global memory (L2 / Infinity-Cache resident: 1 024 waves x <= 31 KB): first D[7], the FD
 // factors (read and written by Jacobian evaluations only, ~1.2 per row), D[6], the Jacobian's base f and the accepted
 // state (both written once per step or accepted step -- fire-and-forget stores -- and read once per Jacobian / row),
@@ -88,12 +95,13 @@ constexpr int LDS_BYTES = 160 * 1024;
 // faster at every depth -- D = 401 +3 %, 541 +6 %, 581 +8 % -- and removes a second code path.)
 // `halves` = 2: a column split over two waves (hc_device.h, Comm<2>) -- each wave holds 64 cpl nodes, the shared tables
 // cover both halves, and the workgroup's two mailboxes sit behind the waves' vectors.
-__host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1)   // how many of the twelve fit, four waves per workgroup
+__host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1)   // how many of the twelve fit
 {
     const int slots = 64 * cpl;
     const int tables = (NTAB * slots * 8 + 4 * slots) * halves;
-    const int boxes = halves == 2 ? (WAVES_PER_BLOCK / 2) * (int)sizeof(PairBox) : 0;
-    const int n = ((LDS_BYTES - tables - boxes) / WAVES_PER_BLOCK - WAVE_SCRATCH * 8) / (slots * 8);
+    const int wpb = wpb_of(cpl, halves);
+    const int boxes = halves == 2 ? (wpb / 2) * (int)sizeof(PairBox) : 0;
+    const int n = ((LDS_BYTES - tables - boxes) / wpb - WAVE_SCRATCH * 8) / (slots * 8);
     return n < NVEC ? n : NVEC;
 }
 __host__ __device__ constexpr int lds_listed(int cpl, int halves = 1)    // ... of the eleven vectors other than the noise
@@ -202,7 +210,7 @@ constexpr int HC_TRACE_N = 20000;
 struct StepArgs {
     const ColumnDev *P;       // device memory, [n_points]
     const IoArgs *io;         // device memory
-    double *wave_spill;       // [grid * 4 waves][spill_vectors(CPL)][SLOTS]: per-wave vectors that do not fit in LDS, or null
+    double *wave_spill;       // [grid * wpb_of(CPL) waves][spill_vectors(CPL)][SLOTS]: per-wave vectors that do not fit in LDS, or null
     const double *tab;        // [n_points][NTAB][SLOTS]
     const int *gtab;          // [NGTAB][SLOTS]
     long long n_members;
@@ -634,7 +642,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB * TSLOTS);     // group ids < 16: a byte each
     double *wave_base = reinterpret_cast<double *>(gtab + 4 * TSLOTS);
     constexpr int NVEC_K = lds_vectors(CPL, HALVES);
-    static_assert(WPB == WAVES_PER_BLOCK, "four waves per workgroup");
+    static_assert(WPB == wpb_of(CPL, HALVES), "the workgroup size the LDS layout was sized for");
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
     // [0] next member of the chunk, [1] its end (-1: no chunk left), [2] point whose tables are in LDS, [3] the chunk's point
     volatile int *chunk_state = reinterpret_cast<volatile int *>(gtab + NGTAB * TSLOTS);
@@ -714,10 +722,10 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         }
         if (member >= A.n_members) break;
     } else {
-        // Several parameter points: the four waves draw members of the workgroup's current chunk from an LDS counter.
-        // A wave that finds the chunk empty waits for the other three (the only barriers of the kernel), then one
+        // Several parameter points: the waves draw members of the workgroup's current chunk from an LDS counter.
+        // A wave that finds the chunk empty waits for the others (the only barriers of the kernel), then one
         // thread takes the next chunk from the device-wide ticket and, when its point differs from the one whose
-        // tables are in LDS, the workgroup reloads them.  Exit: no chunk left, seen by all four waves together.
+        // tables are in LDS, the workgroup reloads them.  Exit: no chunk left, seen by all waves together.
         bool none_left = false;
         for (;;) {
             int m = 0;

@@ -356,7 +356,8 @@ int launch_step(hc_handle *h, const StepArgs &A)
     HIP_TRY(hipMemsetAsync(h->counters.p + 63, 0, sizeof(unsigned long long), h->stream));
     if (h->use_pair()) {
         // split column: a workgroup runs two members at a time, two waves each
-        const long long want = (A.n_members + wpb / 2 - 1) / (wpb / 2);
+        const int pairs = wpb_of(PAIR_CPL, 2) / 2;
+        const long long want = (A.n_members + pairs - 1) / pairs;
         const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->n_cu);
         StepArgs B = A;
         B.tab = h->tab_pair.p;
@@ -381,7 +382,8 @@ int launch_rhs(hc_handle *h, const StepArgs &A, long long row, double *dydt, dou
         StepArgs B = A;
         B.tab = h->tab_pair.p;
         B.gtab = h->gtab_pair.p;
-        const unsigned grid = (unsigned)((A.n_members + wpb / 2 - 1) / (wpb / 2));
+        const int pairs = wpb_of(PAIR_CPL, 2) / 2;
+        const unsigned grid = (unsigned)((A.n_members + pairs - 1) / pairs);
         HIP_TRY(launch_rhs_pair(launch_cfg(h, grid), B, row, dydt));
         return HC_OK;
     }
@@ -433,9 +435,11 @@ int fill_args(hc_handle *h, StepArgs &A)
     A.members_per_point = h->n_members / NP;
     {
         // chunks of one point's members for the multi-point scheduler: >= 8 chunks per workgroup when the ensemble
-        // allows it, <= 128 members each (32 per wave bound the idle time at a chunk's end to ~1.5 %)
+        // allows it, <= 32 members per wave (that bounds the idle time at a chunk's end to ~1.5 %) and never fewer
+        // members than the workgroup has waves
+        const long long waves = wpb_of(h->cpl);     // (several points never run on the split-column kernel)
         long long chunk = h->chunk_members > 0 ? h->chunk_members : (h->n_members + 8LL * h->n_cu - 1) / (8LL * h->n_cu);
-        chunk = std::max<long long>(4, std::min<long long>(chunk, 128));
+        chunk = std::max<long long>(waves, std::min<long long>(chunk, 32 * waves));
         chunk = std::min<long long>(chunk, A.members_per_point);
         A.chunk_members = (int)chunk;
         A.chunks_per_point = (int)((A.members_per_point + chunk - 1) / chunk);
@@ -445,7 +449,7 @@ int fill_args(hc_handle *h, StepArgs &A)
         // deep columns: room for the per-wave vectors LDS cannot hold, for every wave of the persistent grid
         const size_t per_wave = std::max((size_t)spill_vectors(h->cpl) * (size_t)h->slots,
                                          (size_t)spill_vectors(PAIR_CPL, 2) * (size_t)(WAVE * PAIR_CPL));
-        const size_t cnt = (size_t)h->n_cu * WAVES_PER_BLOCK * per_wave;
+        const size_t cnt = (size_t)h->n_cu * MAX_WAVES_PER_BLOCK * per_wave;
         if (h->wave_spill.ensure(cnt)) return HC_ERR_DEVICE;
         A.wave_spill = h->wave_spill.p;
     }
