@@ -1,8 +1,13 @@
-"""Throughput of the generic-exponent kernel (n != 2 and/or lambda != 1): python tools/prof_generic.py [n] [lam] [N] [D]"""
+"""Throughput of the generic-exponent kernel (n != 2 and/or lambda != 1): python tools/prof_generic.py [n] [lam] [N] [D]
+(HC_LIB=<lib.so> selects a development build)"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import numpy as np
+if os.environ.get("HC_LIB"):
+    import pathlib
+    from hydromodel_amd import _lib
+    _lib.LIB_PATH = pathlib.Path(os.environ["HC_LIB"]).resolve()
 from hydromodel_amd.digest import ColumnTables, ForcingDigest
 from hydromodel_amd.ensemble import EnsembleSimulation
 from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
