@@ -1136,7 +1136,8 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
     double pL_pair = 0.0, edge_C = 0.0, edge_f = 0.0, edge_s = 0.0, edge_ym = 0.0;
     int jstar_other = -1, jstar_mine = -1;
     if constexpr (H == 2) {
-        const double pl = readlane_d(top_flux(P, R, y_top, kb_top, th_top, pf_top), WAVE - 1);
+        double pl = 0.0;                          // (the upper half is the critical path in daylight: it skips this)
+        if (comm.half == 1) pl = readlane_d(top_flux(P, R, y_top, kb_top, th_top, pf_top), WAVE - 1);
         bool unsat0[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
