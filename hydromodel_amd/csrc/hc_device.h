@@ -280,14 +280,11 @@ __device__ __forceinline__ double rsqrt_ge1(double x)
 // Columns deeper than 512 nodes are SPLIT over two cooperating wavefronts of one workgroup (waves 2p and 2p + 1): half h
 // owns the nodes [h * 64 CPL, (h + 1) * 64 CPL), again CPL consecutive nodes per lane.  One wave cannot hold the working
 // set of a 640-node column (hipcc 7.2: 1.5 KB of scratch per lane at 10 cells per lane); two waves hold it in two
-// register files with no scratch at all.  What crosses the cut -- the stencil's edge values, every reduction, the
+// register files with 0.2 KB.  What crosses the cut -- the stencil's edge values, every reduction, the
 // coupling of the two tridiagonal blocks -- goes through a mailbox in LDS: double-buffered payload, one sequence counter
 // per half (release store / acquire load at workgroup scope), no s_barrier (the other pair of the workgroup runs another
 // member with its own control flow).  Both halves execute the same sequence of exchanges: every branch that contains
 // one is decided by values both halves hold identically.
-#ifndef HC_PAIR_SLEEP
-#define HC_PAIR_SLEEP 1
-#endif
 struct PairBox {
     double data[2][2][8];      // [exchange parity][half][value]
     unsigned seq[2];           // exchanges posted by each half
@@ -353,31 +350,34 @@ struct Comm<2> {
         }
         const volatile __attribute__((address_space(3))) unsigned *seq = &box->seq[half ^ 1];
         const volatile __attribute__((address_space(3))) double *in = box->data[p][half ^ 1];
-        // everything that steers the loop is made scalar by hand: the compiler cannot see that k, dead and the polled
-        // sequence number are the same in all lanes, and would otherwise run the loop under exec masks
+        // everything that steers the loop is scalar: the awaited number, the polled one (readfirstlane) and the spin
+        // count.  No sleep between polls (tools/dev/xchg_bench.hip: 270 cycles per exchange of one double against 560
+        // with `s_sleep 1` and a per-lane exit flag inside the loop).
         const int want = __builtin_amdgcn_readfirstlane((int)k) + 1;
-        int gone = __builtin_amdgcn_readfirstlane(dead);
-        int spins = 0;
-        for (;;) {
+        k = (unsigned)want;
+        if (__builtin_amdgcn_readfirstlane(dead)) {          // (an earlier exchange timed out: the member is running out)
+#pragma unroll
+            for (int j = 0; j < N; j++) theirs[j] = 0.0;
+            return;
+        }
+        double v[N];
+        bool timed_out = false;
+        for (int spins = 0;;) {
             const int got = __builtin_amdgcn_readfirstlane((int)*seq);
-            double v[N];
 #pragma unroll
             for (int j = 0; j < N; j++) v[j] = in[j];
-            if ((got >= want) | (gone != 0)) {
-#pragma unroll
-                for (int j = 0; j < N; j++) theirs[j] = uniform_d(v[j]);
+            if (got >= want) break;
+            if (++spins > SPIN_LIMIT) {          // every wave must reach an exit
+                timed_out = true;
                 break;
             }
-#if HC_PAIR_SLEEP
-            __builtin_amdgcn_s_sleep(1);
-#endif
-            if (++spins > SPIN_LIMIT) {          // every wave must reach an exit
-                gone = 1;
-                if (lane == 0) atomicAdd(fault, 1ull);
-            }
         }
-        dead = gone;
-        k = (unsigned)want;
+#pragma unroll
+        for (int j = 0; j < N; j++) theirs[j] = uniform_d(v[j]);
+        if (timed_out) {
+            dead = 1;
+            if (lane == 0) atomicAdd(fault, 1ull);
+        }
     }
     // upper half's value first: both halves form the same sum, bit for bit
     __device__ __forceinline__ double sum(double v)
