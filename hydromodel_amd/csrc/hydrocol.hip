@@ -538,6 +538,8 @@ int hc_create(int device_ordinal, hc_handle **out)
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
         h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (const char *e = getenv("HYDROCOL_DEBUG_CUS"))      // measurement hook: a smaller persistent grid
+            if (atoi(e) > 0) h->n_cu = std::min(h->n_cu, atoi(e));
         return HC_OK;
     };
     if (const int rc = init()) {
