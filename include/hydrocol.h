@@ -184,7 +184,8 @@ int hc_synchronize(hc_handle *h);
  * last of those happened: global member id << 24 | forcing row.
  * Test hooks read from the environment at hc_create: HYDROCOL_DEBUG_MAX_ITER (same as hc_set_iteration_budget),
  * HYDROCOL_DEBUG_JAC_REJECT (raises num_jac's retry threshold), HYDROCOL_ROWS_PER_LAUNCH, HYDROCOL_CHUNK_MEMBERS
- * (members per scheduling chunk when several parameter points share a launch). */
+ * (members per scheduling chunk when several parameter points share a launch), HYDROCOL_DEBUG_CUS (a persistent grid of
+ * fewer workgroups than the device has compute units: measurements only). */
 int hc_get_counters(hc_handle *h, uint64_t *out4);
 /* Rows one kernel launch of hc_step_rows covers; hc_step_rows splits longer requests.  Default (and rows = 0): 48 = one
  * simulated day for ensembles of >= 65 536 members, proportionally more for smaller ones (48 x 65 536 / members, at
