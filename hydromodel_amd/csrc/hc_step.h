@@ -784,8 +784,10 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     // runs (tools/prof_depth.py prints a digest of the final state): group ids on demand for CPL 6-8 (+4..10 %),
     // the row-start state in the global region for CPL 9-10 (+4 %).  Both together at CPL = 10 made hipcc 7.2 carry a
     // stale value into the per-row failure count (tools/dev/dbg_failed.py) -- the combination is not used.
-    constexpr bool DEEP = CPL >= 6 && CPL <= 8;   // (measured neutral at CPL = 5; with the split column: 40 % less scratch, 0.8 % slower)
-    constexpr bool DEEPY = CPL >= 9;
+    // (measured neutral at CPL = 5; with the split column: 40 % less scratch, 0.8 % slower; at two waves per SIMD every
+    //  register counts: D = 101 +3 %, D = 192 +11 %)
+    constexpr bool DEEP = (CPL >= 6 && CPL <= 8) || CPL <= 3;
+    constexpr bool DEEPY = CPL >= 9;     // (with DEEP at CPL <= 3: D = 101 +1.6 %, D = 192 -9.5 %: not used)
     static_assert(!(DEEP && DEEPY), "group ids on demand and the row-start state in the global region are not combined");
     int gs_keep[CPL], gp_keep[CPL], gn_keep[CPL];
     if (!DEEP) {
