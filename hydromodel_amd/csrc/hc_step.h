@@ -104,6 +104,18 @@ __host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1)   // how 
     const int n = ((LDS_BYTES - tables - boxes) / wpb - WAVE_SCRATCH * 8) / (slots * 8);
     return n < NVEC ? n : NVEC;
 }
+// Room to spare (two cells per lane, eight waves per workgroup): the Jacobian's three rows and the FD steps -- per-lane
+// arrays that are live from the first group evaluation of a Jacobian to the factorisation, across every RHS evaluation in
+// between -- move from registers to four more per-wave vectors behind the wave's scratch area.  At two waves per SIMD
+// (256 registers) each of them is otherwise a scratch round trip.
+__host__ __device__ constexpr int lds_extra(int cpl, int halves = 1)
+{
+    if (halves != 1 || wpb_of(cpl, halves) != 8) return 0;
+    const int slots = 64 * cpl;
+    const int tables = NTAB * slots * 8 + 4 * slots;
+    const int n = ((LDS_BYTES - tables) / 8 - WAVE_SCRATCH * 8) / (slots * 8);
+    return n >= NVEC + 4 ? 4 : 0;
+}
 __host__ __device__ constexpr int lds_listed(int cpl, int halves = 1)    // ... of the eleven vectors other than the noise
 {
     const int n = lds_vectors(cpl, halves) - 1;
@@ -642,6 +654,9 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB * TSLOTS);     // group ids < 16: a byte each
     double *wave_base = reinterpret_cast<double *>(gtab + 4 * TSLOTS);
     constexpr int NVEC_K = lds_vectors(CPL, HALVES);
+    constexpr int NEXTRA = lds_extra(CPL, HALVES);
+    constexpr bool J_LDS = NEXTRA == 4;
+    constexpr int WSTRIDE = (NVEC_K + NEXTRA) * SLOTS + WAVE_SCRATCH;     // doubles per wave
     static_assert(WPB == wpb_of(CPL, HALVES), "the workgroup size the LDS layout was sized for");
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
     // [0] next member of the chunk, [1] its end (-1: no chunk left), [2] point whose tables are in LDS, [3] the chunk's point
@@ -669,18 +684,39 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     const int hb = HALVES == 2 ? (wave & 1) * SLOTS : 0;          // this wave's first node
     const double *tabw = tab + hb;
     const signed char *gtabw = gtab + hb;
-    double *V = wave_base + (size_t)wave * (NVEC_K * SLOTS + WAVE_SCRATCH);
+    double *V = wave_base + (size_t)wave * WSTRIDE;
     double *ru = V + NVEC_K * SLOTS;
+    double *jx = ru + WAVE_SCRATCH;       // [4][SLOTS] when J_LDS: Jacobian rows (sub, main, super) and FD steps
+#define HC_J_LOAD()                                                        \
+    if constexpr (J_LDS) {                                                 \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
+            const int s_ = c * WAVE + lane;                                \
+            jl[c] = jx[s_];                                                \
+            jd[c] = jx[SLOTS + s_];                                        \
+            ju[c] = jx[2 * SLOTS + s_];                                    \
+            hj[c] = jx[3 * SLOTS + s_];                                    \
+        }                                                                  \
+    }
+#define HC_J_STORE()                                                       \
+    if constexpr (J_LDS) {                                                 \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
+            const int s_ = c * WAVE + lane;                                \
+            jx[s_] = jl[c];                                                \
+            jx[SLOTS + s_] = jd[c];                                        \
+            jx[2 * SLOTS + s_] = ju[c];                                    \
+            jx[3 * SLOTS + s_] = hj[c];                                    \
+        }                                                                  \
+    }
     // f_new[group][row 0], <= 16 groups: row 0 belongs to the upper half, the lower half reads it there
-    double *row0 = (HALVES == 2 && (wave & 1) ? ru - (NVEC_K * SLOTS + WAVE_SCRATCH) : ru) + 108;
+    double *row0 = (HALVES == 2 && (wave & 1) ? ru - WSTRIDE : ru) + 108;
     Comm<HALVES> comm;
     comm.half = HALVES == 2 ? (wave & 1) : 0;
     // the partner wave's noise vector (the lower half's first cell uses n_rnd of the upper half's last node, its
     // top-node cell n_rnd[0])
-    const double *nz_partner = V + (HALVES == 2 ? ((wave & 1) ? -1 : 1) * (NVEC_K * SLOTS + WAVE_SCRATCH) : 0) +
+    const double *nz_partner = V + (HALVES == 2 ? ((wave & 1) ? -1 : 1) * WSTRIDE : 0) +
                                lds_listed(CPL, HALVES) * SLOTS;
     if constexpr (HALVES == 2) {
-        PairBox *boxes = reinterpret_cast<PairBox *>(wave_base + (size_t)WPB * (NVEC_K * SLOTS + WAVE_SCRATCH));
+        PairBox *boxes = reinterpret_cast<PairBox *>(wave_base + (size_t)WPB * WSTRIDE);
         comm.lane = lane;
         comm.k = 0;
         comm.dead = 0;
@@ -940,6 +976,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     yp[c] = psiv[c] = dd[c] = jl[c] = jd[c] = ju[c] = hj[c] = 0.0;
                     scl[c] = 1.0;
                 }
+                HC_J_STORE();
                 int phase = PH_F0;
                 // column parameters: one scalar-memory read per attempt.  (Per RHS evaluation the lone wave sat out
                 // the load latency 24 times per row; for the kernel's lifetime they cost ~60 SGPRs, see DESIGN.md.)
@@ -1113,6 +1150,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         have_f = false;
                         HC_STAMP(PH_JAC_REDO);
                         HC_GROUPS();
+                        HC_J_LOAD();
                         // f = fun(y + h_new * [column small and in group g]); keep the new column where
                         // max_diff * scale_new < max_diff_new * scale  (common.py _sparse_num_jac)
                         __builtin_amdgcn_wave_barrier();
@@ -1162,6 +1200,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             jd[c] = upd[c] != 0.0 ? f[c] : jd[c];
                             ju[c] = uD != 0.0 ? f[c] : ju[c];
                         }
+                        HC_J_STORE();
                         redo_mask &= ~(1 << g);
                         if (redo_mask != 0) {
                             g = __ffs(redo_mask) - 1;
@@ -1180,6 +1219,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     if (phase == PH_JAC) {
                         HC_STAMP(PH_JAC);
                         HC_GROUPS();
+                        HC_J_LOAD();
                         if (g < 0) {
                             HC_SUB(62);
                             // common.num_jac: step h per column from factor, f sign and |y|
@@ -1211,6 +1251,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             }
                             g++;
                         }
+                        HC_J_STORE();
                         HC_SUB_END();
                         if (g < A.n_groups) {
 #pragma unroll
@@ -1222,6 +1263,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     if (phase == C_JAC_FIN) {
                         HC_STAMP(C_JAC_FIN);
                         HC_GROUPS();
+                        HC_J_LOAD();
                         // _sparse_num_jac: per-column max |diff| (rows j-1, j, j+1), its scale, factor update,
                         // J = diff / h.  jac_stage 0 = first look, 1 = after the retry pass below.
                         __builtin_amdgcn_wave_barrier();
@@ -1301,6 +1343,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                 ju[c] = nju[c];
                                 if (vnode[c]) W.template st<V_FAC>(c * WAVE + lane, nfac[c]);
                             }
+                            HC_J_STORE();
                                 jac_stage = 0;
                             if (jac_init) {
                                 // rest of BDF.__init__: D[0] = y, D[1] = f0 * h_abs, order = 1
@@ -1443,6 +1486,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         HC_STAMP(C_NEWTON_BEGIN);
                         if (!have_lu) {
                             HC_STAMP(23);
+                            HC_J_LOAD();
                             lu_factor<CPL>(F, jl, jd, ju, cc, lane, D, comm);
                             HC_STAMP(C_NEWTON_BEGIN);
                             have_lu = 1;
