@@ -822,9 +822,14 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     // stale value into the per-row failure count (tools/dev/dbg_failed.py) -- the combination is not used.
     // (measured neutral at CPL = 5; with the split column: 40 % less scratch, 0.8 % slower; at two waves per SIMD every
     //  register counts: D = 101 +3 %, D = 192 +11 %)
+#ifdef HC_TRY_DEEP_BOTH    // tools/dev: the combination round 2 found miscompiled at CPL = 10 (root-cause builds only)
+    constexpr bool DEEP = (CPL >= 6 && CPL <= 8) || CPL <= 3 || CPL == 10;
+    constexpr bool DEEPY = CPL >= 9;
+#else
     constexpr bool DEEP = (CPL >= 6 && CPL <= 8) || CPL <= 3;
     constexpr bool DEEPY = CPL >= 9;     // (with DEEP at CPL <= 3: D = 101 +1.6 %, D = 192 -9.5 %: not used)
     static_assert(!(DEEP && DEEPY), "group ids on demand and the row-start state in the global region are not combined");
+#endif
     int gs_keep[CPL], gp_keep[CPL], gn_keep[CPL];
     if (!DEEP) {
 #pragma unroll
