@@ -110,10 +110,12 @@ __host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1)   // how 
 // (256 registers) each of them is otherwise a scratch round trip.
 __host__ __device__ constexpr int lds_extra(int cpl, int halves = 1)
 {
+    // (CPL = 4 with four waves would have the room too: measured 1.5 % slower -- at one wave per SIMD a parked register
+    //  is an AGPR move, cheaper than the LDS round trip)
     if (halves != 1 || wpb_of(cpl, halves) != 8) return 0;
     const int slots = 64 * cpl;
     const int tables = NTAB * slots * 8 + 4 * slots;
-    const int n = ((LDS_BYTES - tables) / 8 - WAVE_SCRATCH * 8) / (slots * 8);
+    const int n = ((LDS_BYTES - tables) / wpb_of(cpl, halves) - WAVE_SCRATCH * 8) / (slots * 8);
     return n >= NVEC + 4 ? 4 : 0;
 }
 __host__ __device__ constexpr int lds_listed(int cpl, int halves = 1)    // ... of the eleven vectors other than the noise
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     constexpr bool DEEP = (CPL >= 6 && CPL <= 8) || CPL <= 3 || CPL == 10;
     constexpr bool DEEPY = CPL >= 9;
 #else
-    constexpr bool DEEP = (CPL >= 6 && CPL <= 8) || CPL <= 3;
+    constexpr bool DEEP = (CPL >= 6 && CPL <= 8) || CPL <= 3;     // (CPL = 4, one wave per SIMD: -1 %)
     constexpr bool DEEPY = CPL >= 9;     // (with DEEP at CPL <= 3: D = 101 +1.6 %, D = 192 -9.5 %: not used)
     static_assert(!(DEEP && DEEPY), "group ids on demand and the row-start state in the global region are not combined");
 #endif
