@@ -1,11 +1,15 @@
-// hc_inst.hip -- the kernels of ONE cells-per-lane count (compile with -DHC_INST_CPL=N, N = 2..10): the step kernel and
-// the RHS hook, each for {specialised, generic exponents} x {monitoring, PREDICT lateral flow}.  See hc_launch.h.
+// hc_inst.hip -- the kernels of ONE cells-per-lane count and ONE cell model (compile with -DHC_INST_CPL=N, N = 2..10, and
+// -DHC_INST_SPECIAL=1 | 0: default / generic exponents): the step kernel and the RHS hook, each for {monitoring, PREDICT
+// lateral flow}.  See hc_launch.h.
 #include <cstdlib>
 
 #include "hc_launch.h"
 
 #if !defined(HC_INST_CPL) && !defined(HC_INST_PAIR)
-#error "compile with -DHC_INST_CPL=<cells per lane> or -DHC_INST_PAIR"
+#error "compile with -DHC_INST_CPL=<cells per lane> -DHC_INST_SPECIAL=<0|1> or -DHC_INST_PAIR"
+#endif
+#if defined(HC_INST_CPL) && !defined(HC_INST_SPECIAL)
+#error "compile with -DHC_INST_SPECIAL=1 (default exponents) or 0 (generic exponents) next to -DHC_INST_CPL"
 #endif
 
 #ifdef HC_INST_PAIR
@@ -228,21 +232,18 @@ hipError_t rhs_one(const LaunchCfg &cfg, const StepArgs &A, long long row, doubl
 }  // namespace
 
 template <>
-hipError_t launch_step_cpl<HC_INST_CPL>(const LaunchCfg &cfg, const StepArgs &A)
+hipError_t launch_step_part<HC_INST_CPL, HC_INST_SPECIAL != 0>(const LaunchCfg &cfg, const StepArgs &A)
 {
-    if (cfg.special)
-        return cfg.predict ? step_one<HC_INST_CPL, true, true>(cfg, A) : step_one<HC_INST_CPL, true, false>(cfg, A);
-    return cfg.predict ? step_one<HC_INST_CPL, false, true>(cfg, A) : step_one<HC_INST_CPL, false, false>(cfg, A);
+    constexpr bool S = HC_INST_SPECIAL != 0;
+    return cfg.predict ? step_one<HC_INST_CPL, S, true>(cfg, A) : step_one<HC_INST_CPL, S, false>(cfg, A);
 }
 
 template <>
-hipError_t launch_rhs_cpl<HC_INST_CPL>(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt, double *aux)
+hipError_t launch_rhs_part<HC_INST_CPL, HC_INST_SPECIAL != 0>(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt,
+                                                           double *aux)
 {
-    if (cfg.special)
-        return cfg.predict ? rhs_one<HC_INST_CPL, true, true>(cfg, A, row, dydt, aux)
-                           : rhs_one<HC_INST_CPL, true, false>(cfg, A, row, dydt, aux);
-    return cfg.predict ? rhs_one<HC_INST_CPL, false, true>(cfg, A, row, dydt, aux)
-                       : rhs_one<HC_INST_CPL, false, false>(cfg, A, row, dydt, aux);
+    constexpr bool S = HC_INST_SPECIAL != 0;
+    return cfg.predict ? rhs_one<HC_INST_CPL, S, true>(cfg, A, row, dydt, aux) : rhs_one<HC_INST_CPL, S, false>(cfg, A, row, dydt, aux);
 }
 
 }  // namespace hc

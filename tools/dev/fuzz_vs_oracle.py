@@ -1,13 +1,17 @@
 """Random configurations through the GPU stepper and the CPU oracle: depth (incl. the lane-boundary and split-column
 edges), plugin, exponents, flags (ET / LF / HLIFT / repaired PREDICT), root depth, water-table observation, launch
 partition.  Each case: 3 members, `rows` chained rows from a hydrostatic-like state with host noise.
-    python tools/dev/fuzz_vs_oracle.py [n_cases=40] [seed=1] [rows=20] [--deep]
+    python tools/dev/fuzz_vs_oracle.py [n_cases=40] [seed=1] [rows=20] [--deep] [--only CASE]   (HC_LIB=<lib.so>: a development build)
 Prints one line per case (chained errors for information, the row-by-row replay as the verdict) and a summary; exit
 status 1 if a case leaves the tolerance tiers of DESIGN.md §3."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import numpy as np
+if os.environ.get("HC_LIB"):                              # a development build instead of the shipped library
+    import pathlib
+    from hydromodel_amd import _lib
+    _lib.LIB_PATH = pathlib.Path(os.environ["HC_LIB"]).resolve()
 from hydromodel_amd.digest import ColumnTables, ForcingDigest
 from hydromodel_amd.stepper import EnsembleStepper
 from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
@@ -15,6 +19,7 @@ from oracle.oracle import Oracle
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+ONLY = int(sys.argv[sys.argv.index("--only") + 1]) if "--only" in sys.argv else None   # run that case alone
 DEEP_ONLY = "--deep" in sys.argv                           # depths 513 .. 640 only, water tables around and below the cut too
 rng = np.random.default_rng(seed)
 frame = synthetic_forcing_frame(1)
@@ -55,9 +60,12 @@ for case in range(n_cases):
     first = int(rng.choice([1, 14, 30, 40]))
     nf = int(forcing.refresh[first:first + rows].sum())
     fresh = rng.standard_normal((nf, N, D))
+    rpl = int(rng.choice([1, 3, 7])) if rng.random() < 0.3 else 0
+    if ONLY is not None and case != ONLY:
+        continue                                           # (--only N: the random stream is consumed as usual, nothing runs)
     st = EnsembleStepper(cols, forcing, N)
-    if rng.random() < 0.3:
-        st.set_rows_per_launch(int(rng.choice([1, 3, 7])))
+    if rpl:
+        st.set_rows_per_launch(rpl)
     st.set_state(y0)
     st.set_noise_host(base)
     out = st.step_rows(first, rows, fresh_noise=fresh, want_wtd=True, want_stats=True, want_psi=True)
@@ -84,6 +92,7 @@ for case in range(n_cases):
     n_ok = int(retried[0]) if retried.size else rows          # after a retry the oracle's damped base vector is not tracked here
     st1 = EnsembleStepper(cols, forcing, 1)
     rhs_worst = reg_worst = stiff_worst = 0.0
+    rhs_where = None
     reg_rows = reg_same = seen = 0
     for k in range(n_ok):
         row = first + k
@@ -94,7 +103,10 @@ for case in range(n_cases):
             ref = o.rhs(Oracle.row(forcing.precip[row], forcing.atm[row], forcing.daylight[row], forcing.wtd_obs[row],
                                    wet=int(forcing.wet_season[row])), states[k], base[0])
             got = st1.rhs(row)[0]
-            rhs_worst = max(rhs_worst, float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))))
+            er = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+            if float(er.max()) > rhs_worst:
+                rhs_worst, rhs_where = float(er.max()), (row, int(er.argmax()), float(ref[er.argmax()]), float(got[er.argmax()]),
+                                                         float(states[k][er.argmax()]))
         fz = fresh[seen, 0][None, None, :] if refresh else np.zeros((0,))
         o1 = st1.step_rows(row, 1, fresh_noise=fz, want_stats=True)
         seen += int(refresh)
@@ -113,11 +125,15 @@ for case in range(n_cases):
     # (flux terms ~1e3 divided by C ~ 1e-7: the RHS itself is ill-conditioned) are held to the integrator's own class
     plain = (model == "vrettas_fung" and params["Soil_Properties"]["n"] == 2.0
              and params["Hydraulic_Conductivity"]["Lambda_Exponent"] == 1.0 and not flags["HLIFT"] and not flags["PREDICT"])
-    ok = bool(np.isfinite(out["psi"]).all() and rhs_worst < (1e-5 if flags["HLIFT"] else 1e-7)
+    # (dy/dt below the water table divides flux differences by C dz = epsilon dz ~ 5e-7: the ~1e-14 relative difference of K
+    #  between three chained in-house exp / log and libm's pow at steep exponents shows there as ~1e-6)
+    ok = bool(np.isfinite(out["psi"]).all() and rhs_worst < (1e-5 if (flags["HLIFT"] or not plain) else 1e-7)
               and reg_worst < (1e-5 if plain else 2e-3) and (stiff_worst < 0.5 or flags["HLIFT"] or guard > 0)
               and reg_same >= (0.9 if plain else 0.5) * reg_rows)    # (outside the tight class a 1e-15 difference of a
     # power decides a Newton iteration count now and then: the state tier is the criterion there)
     bad += not ok
+    if not ok and rhs_where:
+        print(f"   worst RHS difference: row {rhs_where[0]} node {rhs_where[1]}: oracle {rhs_where[2]:.15e} GPU {rhs_where[3]:.15e} at psi {rhs_where[4]:.6e}")
     print(f"case {case}: D={D} {model} n={params['Soil_Properties']['n']} lam={params['Hydraulic_Conductivity']['Lambda_Exponent']} "
           f"{''.join(k[0] if v else '-' for k, v in flags.items())} roots={params['Trees']['Max_Root_Depth_cm']:.0f} sat={well['sat_depth']:.0f} "
           f"wtd={wtd_m} rows {first}+{rows}: first row {worst_first:.1e}, all rows {worst:.1e}, statistics {same}/{tot}, wtd {wsame}/{tot}, "

@@ -82,7 +82,7 @@ VALU_CLASSES = ("f64 arith", "f64 trans", "f64 other (min/max/ldexp/frexp/cvt)",
 
 def assemble(cpl, extra):
     out = f"/tmp/hc_marks_cpl{cpl}.s"
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-DHC_INST_CPL={cpl}", "-DHC_MARKS",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-DHC_INST_CPL={cpl}", "-DHC_INST_SPECIAL=1", "-DHC_MARKS",
            *extra, "--cuda-device-only", "-S", "-o", out, "hc_inst.hip"]
     subprocess.run(cmd, check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
     return out
