@@ -73,3 +73,16 @@ def test_product_never_imports_the_oracle():
     for path in (REPO / "hydromodel_amd").rglob("*"):
         if path.suffix in (".py", ".hip", ".h", ".cpp"):
             assert not pat.search(path.read_text()), path
+
+
+def test_every_kernel_unit_is_built_and_the_scheduler_table_names_real_units():
+    """One translation unit per cells-per-lane count (2..10) and cell model, one for the split column; the per-unit
+    scheduler settings (`UNIT_FLAGS`) may only name units that exist, and only as `-mllvm <option>` pairs."""
+    import __graft_entry__ as ge
+    assert tuple(ge.ALL_CPL) == tuple(range(2, 11))
+    units = {(n, sp) for n in ge.ALL_CPL for sp in (0, 1)} | {"pair"}
+    assert set(ge.UNIT_FLAGS) <= units
+    for flags in ge.UNIT_FLAGS.values():
+        assert len(flags) % 2 == 0 and all(f == "-mllvm" for f in flags[0::2]) and all(f.startswith("-amdgpu-") for f in flags[1::2])
+    src = (ge.CSRC / "hc_inst.hip").read_text()
+    assert "HC_INST_SPECIAL" in src and "HC_INST_PAIR" in src
