@@ -820,18 +820,15 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     // the loads are not hoisted back out of the loop).
     // Which of the two is used where is decided by measurement and by bit-equality with the plain layout on Philox
     // runs (tools/prof_depth.py prints a digest of the final state): group ids on demand for CPL 6-8 (+4..10 %),
-    // the row-start state in the global region for CPL 9-10 (+4 %).  Both together at CPL = 10 made hipcc 7.2 carry a
-    // stale value into the per-row failure count (tools/dev/dbg_failed.py) -- the combination is not used.
+    // the row-start state in the global region for CPL 9-10 (+4 %).
     // (measured neutral at CPL = 5; with the split column: 40 % less scratch, 0.8 % slower; at two waves per SIMD every
     //  register counts: D = 101 +3 %, D = 192 +11 %)
-#ifdef HC_TRY_DEEP_BOTH    // tools/dev: the combination round 2 found miscompiled at CPL = 10 (root-cause builds only)
-    constexpr bool DEEP = (CPL >= 6 && CPL <= 8) || CPL <= 3 || CPL == 10;
+    constexpr bool DEEP = CPL >= 6 || CPL <= 3;     // (CPL = 4, one wave per SIMD: -1 %)
+    // the row-start state out of registers: CPL 9-10 (with DEEP at CPL <= 3: D = 101 +1.6 %, D = 192 -9.5 %; at CPL = 8: -3 %).
+    // At CPL 9-10 both are on since round 3 (+7.7 % / +3.5 % on the one-wave kernels; the combination round 2 saw
+    // miscompiled belonged to a noise path that no longer exists -- DESIGN.md §5 "Deep columns";
+    // test_one_wave_kernels_of_the_deepest_columns_keep_their_guards holds the two symptoms of that build against it).
     constexpr bool DEEPY = CPL >= 9;
-#else
-    constexpr bool DEEP = (CPL >= 6 && CPL <= 8) || CPL <= 3;     // (CPL = 4, one wave per SIMD: -1 %)
-    constexpr bool DEEPY = CPL >= 9;     // (with DEEP at CPL <= 3: D = 101 +1.6 %, D = 192 -9.5 %: not used)
-    static_assert(!(DEEP && DEEPY), "group ids on demand and the row-start state in the global region are not combined");
-#endif
     int gs_keep[CPL], gp_keep[CPL], gn_keep[CPL];
     if (!DEEP) {
 #pragma unroll

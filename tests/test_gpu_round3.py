@@ -625,3 +625,63 @@ def test_rhs_at_the_deepest_reference_well_matches_the_reference(gpu, mode, monk
         # hydraulic lift adds flux terms ~1e3 that cancel to ~1e-2 before the division by C ~ 1e-7
         assert e < (1e-4 if fl[3] else 1e-7), (mode, name, e)
     print(f"[{mode}] RHS of 14 constructed states at D = 581 vs the reference: worst {worst:.1e}")
+
+
+@pytest.mark.parametrize("dim_d", [541, 581])
+@pytest.mark.parametrize("build", ["special", "generic", "predict"])
+def test_one_wave_kernels_of_the_deepest_columns_keep_their_guards(gpu, dim_d, build, monkeypatch):
+    """Columns deeper than 512 nodes run on the split-column kernel by default, so the guards of the deep-column builds
+    (launch partition with in-kernel noise; failure accounting with every attempt abandoned -- the two symptoms of round
+    2's wrong builds, DESIGN.md §5 "Deep columns") no longer reach the one-wave kernels of 9 and 10 cells per lane there.
+    Those kernels still serve sweeps at these depths, root zones below node 320 and HYDROCOL_SPLIT_COLUMN=0: the same two
+    guards, on them."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import pressure_head
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")
+    params = default_parameters()
+    if build == "predict":
+        params["Simulation_Flags"]["PREDICT"] = True
+    cols = ColumnTables(params, synthetic_well(dim_d))
+    forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
+    N, rows = 6, 50                                      # crosses the refresh row 48
+    rng = np.random.default_rng(dim_d)
+    y0 = np.tile(cols.z - 300.0, (N, 1)) + rng.standard_normal((N, cols.dim_d))
+    res = []
+    for step in (rows, 1, 7):
+        st = gpu.EnsembleStepper(cols, forcing, N)
+        if build == "generic":
+            st.set_generic_exponents(True)
+        st.set_state(y0)
+        st.set_noise_philox(77, 3)
+        wtd, stats = [], []
+        done = 0
+        while done < rows:
+            n = min(step, rows - done)
+            o = st.step_rows(1 + done, n, want_wtd=True, want_stats=True)
+            wtd.append(o["wtd"]); stats.append(o["stats"])
+            done += n
+        res.append((st.get_state(), np.concatenate(wtd), np.concatenate(stats), st.moments()))
+        st.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
+    assert np.isfinite(res[0][0]).all()
+    # every attempt abandoned: five failures per row and member, the base vector x 0.8 fifteen times
+    y1, _ = pressure_head(cols, cols.por_raw)
+    base = np.random.default_rng(4).standard_normal((3, cols.dim_d))
+    st = gpu.EnsembleStepper(cols, forcing, 3)
+    if build == "generic":
+        st.set_generic_exponents(True)
+    st.set_iteration_budget(3)
+    st.set_state(y1)
+    st.set_noise_host(base)
+    out = st.step_rows(1, 3, fresh_noise=np.zeros((0,)), want_stats=True)
+    assert (out["stats"][:, :, 4] == 5).all() and (out["failed"] == 5).all()
+    c = st.counters()
+    assert c["failed_attempts"] == 45 and c["guard_trips"] == 45
+    expect = base.copy()
+    for _ in range(15):
+        expect = expect * 0.8
+    assert np.array_equal(st.get_noise_base(), expect)
+    st.close()
