@@ -102,6 +102,12 @@ def load():
     return _lib
 
 
+def kernel_hash():
+    """The device-code identity the loaded library was built with (hc_version(): "... kernels <hash>")."""
+    v = load().hc_version().decode()
+    return v.rsplit("kernels ", 1)[1] if "kernels " in v else "unknown"
+
+
 def check(rc):
     if rc != 0:
         raise HcError(f"libhydrocol status {rc}: {load().hc_last_error().decode()}")

@@ -64,7 +64,10 @@ constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 // V_Y0, the state a row starts from, is only needed again when an attempt fails: deep columns (CPL > 5) keep it in the
 // global region instead of registers, shallower ones never use it.  (Parking the Jacobian rows and column steps there
 // as well was measured at D = 401 / 461 / 581: 7 % slower -- the compiler's own scratch placement does better.)
-enum { V_Y = 0, V_FP, V_FAC, V_D0, V_NZ = V_D0 + MAX_ORDER + 3, NVEC = V_NZ + 1, V_Y0 = NVEC };
+enum { V_Y = 0, V_FP, V_FAC, V_D0, V_NZ = V_D0 + MAX_ORDER + 3, NVEC = V_NZ + 1, V_Y0 = NVEC,
+       // TWO layout only: the predicted state / Jacobian base point, the Jacobian rows and FD steps, the factorisation
+       V_YP, V_JL, V_JD, V_JU, V_HJ, V_FWF, V_FWB, V_FL, V_FU, V_FIB, NVEC_TWO };
+constexpr int TWO_LANE_SCALARS = 14;     // per-lane scalars of the factorisation (wx, 1/B, al[6], ga[6]): [14][64] behind the vectors
 #ifdef HC_PROFILE
 constexpr int WAVE_SCRATCH = 256;   // + per wave: 32 cycle sums, 32 entry counts, 32 sub-region entry counts
 #else
@@ -76,11 +79,19 @@ constexpr int WAVE_SCRATCH = 160;
 // second wave fills the dependency stalls of the first.  From four cells per lane on the spill traffic outweighs that
 // (D = 256: 0.63x, D = 300: 0.59x), and three or four waves per SIMD lose at every depth (D = 128: 0.64x / 0.48x).
 // -DHC_WAVES_PER_BLOCK=n forces one count everywhere (A/B builds).
+// Round 4: two waves per SIMD at FOUR and FIVE cells per lane with hand-placed state ("TWO" layout, -DHC_TWO_MASK=<bit per
+// cells-per-lane count>).  Nothing but the Newton-hot vectors (iterate, its noise, psi, d, 1/scale) stays in registers
+// across an RHS evaluation; the factorisation, the Jacobian rows, the FD steps and the predicted state live in the wave's
+// LDS / global vectors and are loaded by the phase that uses them -- see WaveVecs and rank_two below.
+#ifndef HC_TWO_MASK
+#define HC_TWO_MASK 0
+#endif
+__host__ __device__ constexpr bool two_of(int cpl, int halves = 1) { return halves == 1 && cpl >= 4 && ((HC_TWO_MASK >> cpl) & 1); }
 #ifdef HC_WAVES_PER_BLOCK
 __host__ __device__ constexpr int wpb_of(int, int = 1) { return HC_WAVES_PER_BLOCK; }
 constexpr int MAX_WAVES_PER_BLOCK = HC_WAVES_PER_BLOCK;
 #else
-__host__ __device__ constexpr int wpb_of(int cpl, int halves = 1) { return (halves == 1 && cpl <= 3) ? 8 : 4; }
+__host__ __device__ constexpr int wpb_of(int cpl, int halves = 1) { return (halves == 1 && (cpl <= 3 || two_of(cpl))) ? 8 : 4; }
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 #endif
 constexpr int LDS_BYTES = 160 * 1024;
@@ -123,11 +134,32 @@ __host__ __device__ constexpr int lds_listed(int cpl, int halves = 1)    // ... 
     const int n = lds_vectors(cpl, halves) - 1;
     return n < NVEC - 1 ? n : NVEC - 1;
 }
-__host__ __device__ constexpr int spill_vectors(int cpl, int halves = 1) { return NVEC - lds_listed(cpl, halves); }   // incl. V_Y0
+__host__ __device__ constexpr int spill_vectors(int cpl, int halves = 1)   // incl. V_Y0
+{
+    return two_of(cpl, halves) ? NVEC_TWO - lds_vectors(cpl, halves) : NVEC - lds_listed(cpl, halves);
+}
+// doubles of the global region one wave owns
+__host__ __device__ constexpr int spill_doubles(int cpl, int halves = 1)
+{
+    return spill_vectors(cpl, halves) * 64 * cpl + (two_of(cpl, halves) ? TWO_LANE_SCALARS * 64 : 0);
+}
 // rank of a vector in the keep-in-LDS order D0..D5, Y, FP, D6, FAC, D7 (, Y0: never in LDS)
 __host__ __device__ constexpr int vec_rank(int v)
 {
     return v == V_Y0 ? 11 : v == V_Y ? 6 : v == V_FP ? 7 : v == V_FAC ? 9 : v == V_D0 + 6 ? 8 : v == V_D0 + 7 ? 10 : v - V_D0;
+}
+
+// TWO layout: keep-in-LDS order.  The noise vector (read across lanes), the difference rows an order-1 step touches
+// (a row's integration restarts at order 1 and rarely leaves it: 5.9 of 6.1 steps per row at D = 300), then what a
+// Newton iteration reads -- the factorisation in the order the solve consumes it, so that the parts that fall to the
+// global region are the ones needed last -- then the Jacobian rows, the FD steps, the predicted state; the vectors the
+// deep-column kernels already keep in the global region come last.
+__host__ __device__ constexpr int rank_two(int v)
+{
+    return v == V_NZ ? 0 : v == V_D0 ? 1 : v == V_D0 + 1 ? 2 : v == V_D0 + 2 ? 3 : v == V_FWF ? 4 : v == V_FWB ? 5 :
+           v == V_FL ? 6 : v == V_FU ? 7 : v == V_FIB ? 8 : v == V_JL ? 9 : v == V_JD ? 10 : v == V_JU ? 11 : v == V_HJ ? 12 :
+           v == V_YP ? 13 : v == V_D0 + 3 ? 14 : v == V_Y ? 15 : v == V_FP ? 16 : v == V_D0 + 4 ? 17 : v == V_FAC ? 18 :
+           v == V_D0 + 5 ? 19 : v == V_D0 + 6 ? 20 : v == V_D0 + 7 ? 21 : 22 /* V_Y0 */;
 }
 
 // A wave's vectors: `lds` holds the first lds_listed(CPL) of the order above (then the noise vector, if it is in LDS),
@@ -135,22 +167,59 @@ __host__ __device__ constexpr int vec_rank(int v)
 template <int CPL, int HALVES = 1>
 struct WaveVecs {
     static constexpr int SLOTS = WAVE * CPL;
-    static constexpr int N_LDS = lds_listed(CPL, HALVES);
+    static constexpr bool TWO = two_of(CPL, HALVES);
+    static constexpr int N_LDS = TWO ? lds_vectors(CPL, HALVES) : lds_listed(CPL, HALVES);
     double *lds;
     __attribute__((address_space(1))) double *spill;
     template <int VEC>
     __device__ __forceinline__ double ld(int slot) const
     {
-        if constexpr (VEC == V_NZ) return lds[N_LDS * SLOTS + slot];
-        else if constexpr (vec_rank(VEC) < N_LDS) return lds[vec_rank(VEC) * SLOTS + slot];
-        else return spill[(vec_rank(VEC) - N_LDS) * SLOTS + slot];
+        if constexpr (TWO) {
+            if constexpr (rank_two(VEC) < N_LDS) return lds[rank_two(VEC) * SLOTS + slot];
+            else return gld((rank_two(VEC) - N_LDS) * SLOTS * 8, slot * 8);
+        } else {
+            static_assert(VEC <= V_Y0, "a vector of the TWO layout");
+            if constexpr (VEC == V_NZ) return lds[N_LDS * SLOTS + slot];
+            else if constexpr (vec_rank(VEC) < N_LDS) return lds[vec_rank(VEC) * SLOTS + slot];
+            else return spill[(vec_rank(VEC) - N_LDS) * SLOTS + slot];
+        }
     }
     template <int VEC>
     __device__ __forceinline__ void st(int slot, double v) const
     {
-        if constexpr (VEC == V_NZ) lds[N_LDS * SLOTS + slot] = v;
-        else if constexpr (vec_rank(VEC) < N_LDS) lds[vec_rank(VEC) * SLOTS + slot] = v;
-        else spill[(vec_rank(VEC) - N_LDS) * SLOTS + slot] = v;
+        if constexpr (TWO) {
+            if constexpr (rank_two(VEC) < N_LDS) lds[rank_two(VEC) * SLOTS + slot] = v;
+            else gst((rank_two(VEC) - N_LDS) * SLOTS * 8, slot * 8, v);
+        } else {
+            static_assert(VEC <= V_Y0, "a vector of the TWO layout");
+            if constexpr (VEC == V_NZ) lds[N_LDS * SLOTS + slot] = v;
+            else if constexpr (vec_rank(VEC) < N_LDS) lds[vec_rank(VEC) * SLOTS + slot] = v;
+            else spill[(vec_rank(VEC) - N_LDS) * SLOTS + slot] = v;
+        }
+    }
+    // TWO layout: per-lane scalar k of the factorisation
+    __device__ __forceinline__ double ldS(int k, int lane) const { return gld((NVEC_TWO - N_LDS) * SLOTS * 8, (k * WAVE + lane) * 8); }
+    __device__ __forceinline__ void stS(int k, int lane, double v) const { gst((NVEC_TWO - N_LDS) * SLOTS * 8, (k * WAVE + lane) * 8, v); }
+    // TWO layout: the wave's global region through a buffer resource -- scalar base + scalar vector offset + per-lane
+    // byte offset + immediate, ONE address VGPR for every access (as plain global pointers hipcc keeps a 64-bit VGPR
+    // address per vector and cell, ~170 registers, and spills them); out-of-range accesses are dropped by the hardware
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ void bind(double *region_base)
+    {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(region_base, 0, spill_doubles(CPL, HALVES) * 8, 0x00020000);
+    }
+    __device__ __forceinline__ double gld(int vec_bytes, int lane_bytes) const
+    {
+        const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, vec_bytes, 0);
+        return __hiloint2double((int)r.y, (int)r.x);
+    }
+    __device__ __forceinline__ void gst(int vec_bytes, int lane_bytes, double v) const
+    {
+        v2u_t r;
+        r.x = (unsigned)__double2loint(v);
+        r.y = (unsigned)__double2hiint(v);
+        __builtin_amdgcn_raw_buffer_store_b64(r, rsrc, lane_bytes, vec_bytes, 0);
     }
     // D[k]: k is a constant after unrolling, the switch folds away
     __device__ __forceinline__ double ldD(int k, int slot) const
@@ -658,6 +727,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     constexpr int NVEC_K = lds_vectors(CPL, HALVES);
     constexpr int NEXTRA = lds_extra(CPL, HALVES);
     constexpr bool J_LDS = NEXTRA == 4;
+    constexpr bool TWO = two_of(CPL, HALVES);       // hand-placed state, two waves per SIMD (see two_of)
     constexpr int WSTRIDE = (NVEC_K + NEXTRA) * SLOTS + WAVE_SCRATCH;     // doubles per wave
     static_assert(WPB == wpb_of(CPL, HALVES), "the workgroup size the LDS layout was sized for");
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
@@ -698,6 +768,14 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             ju[c] = jx[2 * SLOTS + s_];                                    \
             hj[c] = jx[3 * SLOTS + s_];                                    \
         }                                                                  \
+    } else if constexpr (TWO) {                                            \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
+            const int s_ = c * WAVE + lane;                                \
+            jl[c] = W.template ld<V_JL>(s_);                               \
+            jd[c] = W.template ld<V_JD>(s_);                               \
+            ju[c] = W.template ld<V_JU>(s_);                               \
+            hj[c] = W.template ld<V_HJ>(s_);                               \
+        }                                                                  \
     }
 #define HC_J_STORE()                                                       \
     if constexpr (J_LDS) {                                                 \
@@ -708,6 +786,58 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             jx[2 * SLOTS + s_] = ju[c];                                    \
             jx[3 * SLOTS + s_] = hj[c];                                    \
         }                                                                  \
+    } else if constexpr (TWO) {                                            \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
+            const int s_ = c * WAVE + lane;                                \
+            W.template st<V_JL>(s_, jl[c]);                                \
+            W.template st<V_JD>(s_, jd[c]);                                \
+            W.template st<V_JU>(s_, ju[c]);                                \
+            W.template st<V_HJ>(s_, hj[c]);                                \
+        }                                                                  \
+    }
+// TWO layout: the factorisation is written once per lu_factor and read by every Newton iteration (no register of it is
+// live across an RHS evaluation); the predicted state / Jacobian base point likewise
+#define HC_F_STORE()                                                       \
+    if constexpr (TWO) {                                                   \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
+            const int s_ = c * WAVE + lane;                                \
+            W.template st<V_FWF>(s_, F.wf[c]);                             \
+            W.template st<V_FWB>(s_, F.wb[c]);                             \
+            W.template st<V_FL>(s_, F.l[c]);                               \
+            W.template st<V_FU>(s_, F.u[c]);                               \
+            W.template st<V_FIB>(s_, F.ib[c]);                             \
+        }                                                                  \
+        W.stS(0, lane, F.wx);                                              \
+        W.stS(1, lane, F.invB);                                            \
+        _Pragma("unroll") for (int q = 0; q < 6; q++) {                    \
+            W.stS(2 + q, lane, F.al[q]);                                   \
+            W.stS(8 + q, lane, F.ga[q]);                                   \
+        }                                                                  \
+    }
+#define HC_F_LOAD()                                                        \
+    if constexpr (TWO) {                                                   \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
+            const int s_ = c * WAVE + lane;                                \
+            F.wf[c] = W.template ld<V_FWF>(s_);                            \
+            F.wb[c] = W.template ld<V_FWB>(s_);                            \
+            F.l[c] = W.template ld<V_FL>(s_);                              \
+            F.u[c] = W.template ld<V_FU>(s_);                              \
+            F.ib[c] = W.template ld<V_FIB>(s_);                            \
+        }                                                                  \
+        F.wx = W.ldS(0, lane);                                             \
+        F.invB = W.ldS(1, lane);                                           \
+        _Pragma("unroll") for (int q = 0; q < 6; q++) {                    \
+            F.al[q] = W.ldS(2 + q, lane);                                  \
+            F.ga[q] = W.ldS(8 + q, lane);                                  \
+        }                                                                  \
+    }
+#define HC_YP_STORE()                                                                              \
+    if constexpr (TWO) {                                                                           \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) W.template st<V_YP>(c * WAVE + lane, yp[c]); \
+    }
+#define HC_YP_LOAD()                                                                               \
+    if constexpr (TWO) {                                                                           \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) yp[c] = W.template ld<V_YP>(c * WAVE + lane); \
     }
     // f_new[group][row 0], <= 16 groups: row 0 belongs to the upper half, the lower half reads it there
     double *row0 = (HALVES == 2 && (wave & 1) ? ru - WSTRIDE : ru) + 108;
@@ -736,8 +866,12 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #endif
     WaveVecs<CPL, HALVES> W;
     W.lds = V;
+    // (TWO: the wave index as a scalar, so that the region's base is an SGPR pair and every access is "scalar base +
+    //  lane offset + immediate" -- with a per-lane base hipcc keeps one 64-bit VGPR address per vector and cell,
+    //  ~170 registers of them, and spills those)
     W.spill = (__attribute__((address_space(1))) double *)A.wave_spill +
-              ((size_t)blockIdx.x * WPB + wave) * ((size_t)spill_vectors(CPL, HALVES) * SLOTS);
+              ((size_t)blockIdx.x * WPB + (TWO ? uniform_i(wave) : wave)) * (size_t)spill_doubles(CPL, HALVES);
+    if constexpr (TWO) W.bind(A.wave_spill + ((size_t)blockIdx.x * WPB + uniform_i(wave)) * (size_t)spill_doubles(CPL, HALVES));
     change_D_init(ru, lane);
     const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
@@ -823,12 +957,12 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     // the row-start state in the global region for CPL 9-10 (+4 %).
     // (measured neutral at CPL = 5; with the split column: 40 % less scratch, 0.8 % slower; at two waves per SIMD every
     //  register counts: D = 101 +3 %, D = 192 +11 %)
-    constexpr bool DEEP = CPL >= 6 || CPL <= 3;     // (CPL = 4, one wave per SIMD: -1 %)
+    constexpr bool DEEP = CPL >= 6 || CPL <= 3 || TWO;     // (CPL = 4, one wave per SIMD: -1 %)
     // the row-start state out of registers: CPL 9-10 (with DEEP at CPL <= 3: D = 101 +1.6 %, D = 192 -9.5 %; at CPL = 8: -3 %).
     // At CPL 9-10 both are on since round 3 (+7.7 % / +3.5 % on the one-wave kernels; the combination round 2 saw
     // miscompiled belonged to a noise path that no longer exists -- DESIGN.md §5 "Deep columns";
     // test_one_wave_kernels_of_the_deepest_columns_keep_their_guards holds the two symptoms of that build against it).
-    constexpr bool DEEPY = CPL >= 9;
+    constexpr bool DEEPY = CPL >= 9 || TWO;
     int gs_keep[CPL], gp_keep[CPL], gn_keep[CPL];
     if (!DEEP) {
 #pragma unroll
@@ -1049,6 +1183,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             yp[c] = y0v[c];                   // Jacobian base point
                             ycur[c] = y0v[c] + h0 * f[c];
                         }
+                        HC_YP_STORE();
                         phase = PH_F1;
                     }
                     if (phase == PH_F1 && have_f) {
@@ -1083,6 +1218,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             for (int c = 0; c < CPL; c++) W.template st<V_FP>(c * WAVE + lane, f[c]);
                         }
                         bool converged = false, failed_newton = false;
+                        HC_F_LOAD();
                         {
                             double dy[CPL];
 #pragma unroll
@@ -1155,6 +1291,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         HC_STAMP(PH_JAC_REDO);
                         HC_GROUPS();
                         HC_J_LOAD();
+                        HC_YP_LOAD();
                         // f = fun(y + h_new * [column small and in group g]); keep the new column where
                         // max_diff * scale_new < max_diff_new * scale  (common.py _sparse_num_jac)
                         __builtin_amdgcn_wave_barrier();
@@ -1224,6 +1361,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         HC_STAMP(PH_JAC);
                         HC_GROUPS();
                         HC_J_LOAD();
+                        HC_YP_LOAD();
                         if (g < 0) {
                             HC_SUB(62);
                             // common.num_jac: step h per column from factor, f sign and |y|
@@ -1268,6 +1406,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         HC_STAMP(C_JAC_FIN);
                         HC_GROUPS();
                         HC_J_LOAD();
+                        HC_YP_LOAD();
                         // _sparse_num_jac: per-column max |diff| (rows j-1, j, j+1), its scale, factor update,
                         // J = diff / h.  jac_stage 0 = first look, 1 = after the retry pass below.
                         __builtin_amdgcn_wave_barrier();
@@ -1363,6 +1502,10 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             } else {
                                 have_lu = 0;
                                 current_jac = 1;
+                                if constexpr (TWO) {       // (C_NEWTON_BEGIN's `ycur = yp`, while yp is in registers)
+#pragma unroll
+                                    for (int c = 0; c < CPL; c++) ycur[c] = yp[c];
+                                }
                                 phase = C_NEWTON_BEGIN;
                             }
                         }
@@ -1483,6 +1626,11 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #pragma unroll
                             for (int c = 0; c < CPL; c++) scl[c] = fast_div(1.0, ATOL + RTOL * fabs(yp[c]));
                             cc = h / alpha_k(order);
+                            HC_YP_STORE();
+                            if constexpr (TWO) {           // (C_NEWTON_BEGIN's `ycur = yp`, while yp is in registers)
+#pragma unroll
+                                for (int c = 0; c < CPL; c++) ycur[c] = yp[c];
+                            }
                             phase = C_NEWTON_BEGIN;
                         }
                     }
@@ -1492,6 +1640,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             HC_STAMP(23);
                             HC_J_LOAD();
                             lu_factor<CPL>(F, jl, jd, ju, cc, lane, D, comm);
+                            HC_F_STORE();
                             HC_STAMP(C_NEWTON_BEGIN);
                             have_lu = 1;
                             nlu++;
@@ -1499,7 +1648,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #pragma unroll
                         for (int c = 0; c < CPL; c++) {
                             dd[c] = 0.0;
-                            ycur[c] = yp[c];
+                            if constexpr (!TWO) ycur[c] = yp[c];
                         }
                         newton_k = 0;
                         dy_norm_old = -1.0;

@@ -447,8 +447,7 @@ int fill_args(hc_handle *h, StepArgs &A)
     }
     {
         // deep columns: room for the per-wave vectors LDS cannot hold, for every wave of the persistent grid
-        const size_t per_wave = std::max((size_t)spill_vectors(h->cpl) * (size_t)h->slots,
-                                         (size_t)spill_vectors(PAIR_CPL, 2) * (size_t)(WAVE * PAIR_CPL));
+        const size_t per_wave = std::max((size_t)spill_doubles(h->cpl), (size_t)spill_doubles(PAIR_CPL, 2));
         const size_t cnt = (size_t)h->n_cu * MAX_WAVES_PER_BLOCK * per_wave;
         if (h->wave_spill.ensure(cnt)) return HC_ERR_DEVICE;
         A.wave_spill = h->wave_spill.p;
@@ -512,7 +511,11 @@ int fill_args(hc_handle *h, StepArgs &A)
 extern "C" {
 
 const char *hc_last_error(void) { return g_err.c_str(); }
-const char *hc_version(void) { return "hydrocol 0.1 (gfx950)"; }
+#ifndef HC_KERNEL_HASH
+#define HC_KERNEL_HASH "unknown"
+#endif
+// "... kernels <hash>": identity of the device code (sources + compile flags + compiler, __graft_entry__.kernel_hash)
+const char *hc_version(void) { return "hydrocol 0.4 (gfx950) kernels " HC_KERNEL_HASH; }
 
 int hc_create(int device_ordinal, hc_handle **out)
 {

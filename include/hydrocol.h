@@ -91,7 +91,8 @@ typedef struct {
 int hc_create(int device_ordinal, hc_handle **out);
 int hc_destroy(hc_handle *h);
 const char *hc_last_error(void);
-const char *hc_version(void);
+const char *hc_version(void);   /* "hydrocol <v> (gfx950) kernels <hash>": <hash> identifies the device code (kernel
+                                      sources + compile flags + compiler) -- the key of profiles/pmc_constants.json */
 
 int hc_set_column(hc_handle *h, const hc_column_params *p, const double *node_tabs,
                   const double *mid_tabs, const int32_t *groups);

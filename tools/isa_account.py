@@ -61,6 +61,10 @@ def classify(op):
         return "LDS bpermute"
     if op.startswith("ds_"):
         return "LDS"
+    if op.startswith("scratch_load"):
+        return "scratch load (spill)"
+    if op.startswith("scratch_store"):
+        return "scratch store (spill)"
     if op.startswith(("global_", "flat_", "buffer_", "scratch_")):
         return "VMEM"
     if op.startswith("s_waitcnt"):
