@@ -200,9 +200,9 @@ namespace {
 template <int CPL, bool SPECIAL, bool PREDICT>
 hipError_t step_one(const LaunchCfg &cfg, const StepArgs &A)
 {
-    constexpr int WPB = wpb_of(CPL);
+    constexpr int WPB = wpb_of(CPL, 1, SPECIAL);
     auto kern = step_kernel<CPL, SPECIAL, WPB, PREDICT>;
-    const size_t lds = step_lds_bytes(CPL, WPB);
+    const size_t lds = step_lds_bytes(CPL, WPB, 1, SPECIAL);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
@@ -213,11 +213,11 @@ hipError_t step_one(const LaunchCfg &cfg, const StepArgs &A)
 template <int CPL, bool SPECIAL, bool PREDICT>
 hipError_t rhs_one(const LaunchCfg &cfg, const StepArgs &A, long long row, double *dydt, double *aux)
 {
-    constexpr int WPB = wpb_of(CPL);
+    constexpr int WPB = wpb_of(CPL, 1, SPECIAL);
     auto kern = rhs_kernel<CPL, SPECIAL, WPB, PREDICT>;
 #ifdef HC_PROFILE
     // diagnostic build: the step kernel's occupancy (one workgroup per CU) unless HYDROCOL_RHS_LDS_KB says otherwise
-    size_t lds = step_lds_bytes(CPL, WPB);
+    size_t lds = step_lds_bytes(CPL, WPB, 1, SPECIAL);
     if (const char *e = getenv("HYDROCOL_RHS_LDS_KB")) lds = std::max(rhs_lds_bytes(CPL, WPB), (size_t)atoll(e) * 1024);
 #else
     const size_t lds = rhs_lds_bytes(CPL, WPB);

@@ -18,11 +18,11 @@ struct LaunchCfg {
     bool predict;        // repaired PREDICT lateral flow compiled in
 };
 
-inline size_t step_lds_bytes(int cpl, int wpb, int halves = 1)
+inline size_t step_lds_bytes(int cpl, int wpb, int halves = 1, bool special = true)
 {
     const size_t slots = (size_t)WAVE * cpl;
     return (NTAB * slots * 8 + 4 * slots * 1) * halves +
-           (size_t)wpb * ((size_t)(lds_vectors(cpl, halves) + lds_extra(cpl, halves)) * slots + WAVE_SCRATCH) * 8 +
+           (size_t)wpb * ((size_t)(lds_vectors(cpl, halves, special) + lds_extra(cpl, halves, special)) * slots + WAVE_SCRATCH) * 8 +
            (halves == 2 ? (size_t)(wpb / 2) * sizeof(PairBox) : 0);
 }
 inline size_t rhs_lds_bytes(int cpl, int wpb)

@@ -83,15 +83,27 @@ constexpr int WAVE_SCRATCH = 160;
 // cells-per-lane count>).  Nothing but the Newton-hot vectors (iterate, its noise, psi, d, 1/scale) stays in registers
 // across an RHS evaluation; the factorisation, the Jacobian rows, the FD steps and the predicted state live in the wave's
 // LDS / global vectors and are loaded by the phase that uses them -- see WaveVecs and rank_two below.
+// Measured (profiles/r04_two_layout_ab.txt, state digests identical under -ffp-contract=on): default exponents 4 cells
+// per lane 1.25x, 5 cells 1.12x; generic exponents 4 cells 1.21x, 5 cells 0.92x (the generic cell model's working set
+// does not fit beside the Newton-hot vectors); 6 / 7 / 8 cells 0.84 / 0.77 / 0.49x (LDS holds 5 / 4 / 3 vectors a wave).
 #ifndef HC_TWO_MASK
-#define HC_TWO_MASK 0
+#define HC_TWO_MASK ((1 << 4) | (1 << 5))      // default exponents: bit per cells-per-lane count
 #endif
-__host__ __device__ constexpr bool two_of(int cpl, int halves = 1) { return halves == 1 && cpl >= 4 && ((HC_TWO_MASK >> cpl) & 1); }
+#ifndef HC_TWO_MASK_GENERIC
+#define HC_TWO_MASK_GENERIC (1 << 4)           // generic exponents
+#endif
+__host__ __device__ constexpr bool two_of(int cpl, int halves = 1, bool special = true)
+{
+    return halves == 1 && cpl >= 4 && (((special ? HC_TWO_MASK : HC_TWO_MASK_GENERIC) >> cpl) & 1);
+}
 #ifdef HC_WAVES_PER_BLOCK
-__host__ __device__ constexpr int wpb_of(int, int = 1) { return HC_WAVES_PER_BLOCK; }
+__host__ __device__ constexpr int wpb_of(int, int = 1, bool = true) { return HC_WAVES_PER_BLOCK; }
 constexpr int MAX_WAVES_PER_BLOCK = HC_WAVES_PER_BLOCK;
 #else
-__host__ __device__ constexpr int wpb_of(int cpl, int halves = 1) { return (halves == 1 && (cpl <= 3 || two_of(cpl))) ? 8 : 4; }
+__host__ __device__ constexpr int wpb_of(int cpl, int halves = 1, bool special = true)
+{
+    return (halves == 1 && (cpl <= 3 || two_of(cpl, halves, special))) ? 8 : 4;
+}
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 #endif
 constexpr int LDS_BYTES = 160 * 1024;
@@ -106,11 +118,11 @@ constexpr int LDS_BYTES = 160 * 1024;
 // faster at every depth -- D = 401 +3 %, 541 +6 %, 581 +8 % -- and removes a second code path.)
 // `halves` = 2: a column split over two waves (hc_device.h, Comm<2>) -- each wave holds 64 cpl nodes, the shared tables
 // cover both halves, and the workgroup's two mailboxes sit behind the waves' vectors.
-__host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1)   // how many of the twelve fit
+__host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1, bool special = true)   // how many of the twelve fit
 {
     const int slots = 64 * cpl;
     const int tables = (NTAB * slots * 8 + 4 * slots) * halves;
-    const int wpb = wpb_of(cpl, halves);
+    const int wpb = wpb_of(cpl, halves, special);
     const int boxes = halves == 2 ? (wpb / 2) * (int)sizeof(PairBox) : 0;
     const int n = ((LDS_BYTES - tables - boxes) / wpb - WAVE_SCRATCH * 8) / (slots * 8);
     return n < NVEC ? n : NVEC;
@@ -119,29 +131,29 @@ __host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1)   // how 
 // arrays that are live from the first group evaluation of a Jacobian to the factorisation, across every RHS evaluation in
 // between -- move from registers to four more per-wave vectors behind the wave's scratch area.  At two waves per SIMD
 // (256 registers) each of them is otherwise a scratch round trip.
-__host__ __device__ constexpr int lds_extra(int cpl, int halves = 1)
+__host__ __device__ constexpr int lds_extra(int cpl, int halves = 1, bool special = true)
 {
     // (CPL = 4 with four waves would have the room too: measured 1.5 % slower -- at one wave per SIMD a parked register
     //  is an AGPR move, cheaper than the LDS round trip)
-    if (halves != 1 || wpb_of(cpl, halves) != 8) return 0;
+    if (halves != 1 || wpb_of(cpl, halves, special) != 8) return 0;
     const int slots = 64 * cpl;
     const int tables = NTAB * slots * 8 + 4 * slots;
-    const int n = ((LDS_BYTES - tables) / wpb_of(cpl, halves) - WAVE_SCRATCH * 8) / (slots * 8);
+    const int n = ((LDS_BYTES - tables) / wpb_of(cpl, halves, special) - WAVE_SCRATCH * 8) / (slots * 8);
     return n >= NVEC + 4 ? 4 : 0;
 }
-__host__ __device__ constexpr int lds_listed(int cpl, int halves = 1)    // ... of the eleven vectors other than the noise
+__host__ __device__ constexpr int lds_listed(int cpl, int halves = 1, bool special = true)    // ... of the eleven vectors other than the noise
 {
-    const int n = lds_vectors(cpl, halves) - 1;
+    const int n = lds_vectors(cpl, halves, special) - 1;
     return n < NVEC - 1 ? n : NVEC - 1;
 }
-__host__ __device__ constexpr int spill_vectors(int cpl, int halves = 1)   // incl. V_Y0
+__host__ __device__ constexpr int spill_vectors(int cpl, int halves = 1, bool special = true)   // incl. V_Y0
 {
-    return two_of(cpl, halves) ? NVEC_TWO - lds_vectors(cpl, halves) : NVEC - lds_listed(cpl, halves);
+    return two_of(cpl, halves, special) ? NVEC_TWO - lds_vectors(cpl, halves, special) : NVEC - lds_listed(cpl, halves, special);
 }
 // doubles of the global region one wave owns
-__host__ __device__ constexpr int spill_doubles(int cpl, int halves = 1)
+__host__ __device__ constexpr int spill_doubles(int cpl, int halves = 1, bool special = true)
 {
-    return spill_vectors(cpl, halves) * 64 * cpl + (two_of(cpl, halves) ? TWO_LANE_SCALARS * 64 : 0);
+    return spill_vectors(cpl, halves, special) * 64 * cpl + (two_of(cpl, halves, special) ? TWO_LANE_SCALARS * 64 : 0);
 }
 // rank of a vector in the keep-in-LDS order D0..D5, Y, FP, D6, FAC, D7 (, Y0: never in LDS)
 __host__ __device__ constexpr int vec_rank(int v)
@@ -164,11 +176,11 @@ __host__ __device__ constexpr int rank_two(int v)
 
 // A wave's vectors: `lds` holds the first lds_listed(CPL) of the order above (then the noise vector, if it is in LDS),
 // `spill` the rest.  VEC is a compile-time id; the D-row accessors take the row as an unrolled loop index.
-template <int CPL, int HALVES = 1>
+template <int CPL, int HALVES = 1, bool SP = true>
 struct WaveVecs {
     static constexpr int SLOTS = WAVE * CPL;
-    static constexpr bool TWO = two_of(CPL, HALVES);
-    static constexpr int N_LDS = TWO ? lds_vectors(CPL, HALVES) : lds_listed(CPL, HALVES);
+    static constexpr bool TWO = two_of(CPL, HALVES, SP);
+    static constexpr int N_LDS = TWO ? lds_vectors(CPL, HALVES, SP) : lds_listed(CPL, HALVES, SP);
     double *lds;
     __attribute__((address_space(1))) double *spill;
     template <int VEC>
@@ -207,7 +219,7 @@ struct WaveVecs {
     __amdgpu_buffer_rsrc_t rsrc;
     __device__ __forceinline__ void bind(double *region_base)
     {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(region_base, 0, spill_doubles(CPL, HALVES) * 8, 0x00020000);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(region_base, 0, spill_doubles(CPL, HALVES, SP) * 8, 0x00020000);
     }
     __device__ __forceinline__ double gld(int vec_bytes, int lane_bytes) const
     {
@@ -724,12 +736,16 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     double *tab = lds;
     signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB * TSLOTS);     // group ids < 16: a byte each
     double *wave_base = reinterpret_cast<double *>(gtab + 4 * TSLOTS);
-    constexpr int NVEC_K = lds_vectors(CPL, HALVES);
-    constexpr int NEXTRA = lds_extra(CPL, HALVES);
+    constexpr int NVEC_K = lds_vectors(CPL, HALVES, SPECIAL);
+    constexpr int NEXTRA = lds_extra(CPL, HALVES, SPECIAL);
     constexpr bool J_LDS = NEXTRA == 4;
-    constexpr bool TWO = two_of(CPL, HALVES);       // hand-placed state, two waves per SIMD (see two_of)
+    constexpr bool TWO = two_of(CPL, HALVES, SPECIAL);       // hand-placed state, two waves per SIMD (see two_of)
+#ifndef HC_TWO_PARTS
+#define HC_TWO_PARTS 31       // development: bit 0 factorisation, 1 Jacobian rows, 2 predicted state, 3 group ids, 4 row-start state
+#endif
+    constexpr bool TWO_F = TWO && (HC_TWO_PARTS & 1), TWO_J = TWO && (HC_TWO_PARTS & 2), TWO_YP = TWO && (HC_TWO_PARTS & 4);
     constexpr int WSTRIDE = (NVEC_K + NEXTRA) * SLOTS + WAVE_SCRATCH;     // doubles per wave
-    static_assert(WPB == wpb_of(CPL, HALVES), "the workgroup size the LDS layout was sized for");
+    static_assert(WPB == wpb_of(CPL, HALVES, SPECIAL), "the workgroup size the LDS layout was sized for");
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
     // [0] next member of the chunk, [1] its end (-1: no chunk left), [2] point whose tables are in LDS, [3] the chunk's point
     volatile int *chunk_state = reinterpret_cast<volatile int *>(gtab + NGTAB * TSLOTS);
@@ -768,7 +784,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             ju[c] = jx[2 * SLOTS + s_];                                    \
             hj[c] = jx[3 * SLOTS + s_];                                    \
         }                                                                  \
-    } else if constexpr (TWO) {                                            \
+    } else if constexpr (TWO_J) {                                          \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
             const int s_ = c * WAVE + lane;                                \
             jl[c] = W.template ld<V_JL>(s_);                               \
@@ -786,7 +802,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             jx[2 * SLOTS + s_] = ju[c];                                    \
             jx[3 * SLOTS + s_] = hj[c];                                    \
         }                                                                  \
-    } else if constexpr (TWO) {                                            \
+    } else if constexpr (TWO_J) {                                          \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
             const int s_ = c * WAVE + lane;                                \
             W.template st<V_JL>(s_, jl[c]);                                \
@@ -798,7 +814,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 // TWO layout: the factorisation is written once per lu_factor and read by every Newton iteration (no register of it is
 // live across an RHS evaluation); the predicted state / Jacobian base point likewise
 #define HC_F_STORE()                                                       \
-    if constexpr (TWO) {                                                   \
+    if constexpr (TWO_F) {                                                   \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
             const int s_ = c * WAVE + lane;                                \
             W.template st<V_FWF>(s_, F.wf[c]);                             \
@@ -815,7 +831,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         }                                                                  \
     }
 #define HC_F_LOAD()                                                        \
-    if constexpr (TWO) {                                                   \
+    if constexpr (TWO_F) {                                                   \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
             const int s_ = c * WAVE + lane;                                \
             F.wf[c] = W.template ld<V_FWF>(s_);                            \
@@ -832,11 +848,11 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         }                                                                  \
     }
 #define HC_YP_STORE()                                                                              \
-    if constexpr (TWO) {                                                                           \
+    if constexpr (TWO_YP) {                                                                           \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) W.template st<V_YP>(c * WAVE + lane, yp[c]); \
     }
 #define HC_YP_LOAD()                                                                               \
-    if constexpr (TWO) {                                                                           \
+    if constexpr (TWO_YP) {                                                                           \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) yp[c] = W.template ld<V_YP>(c * WAVE + lane); \
     }
     // f_new[group][row 0], <= 16 groups: row 0 belongs to the upper half, the lower half reads it there
@@ -846,7 +862,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     // the partner wave's noise vector (the lower half's first cell uses n_rnd of the upper half's last node, its
     // top-node cell n_rnd[0])
     const double *nz_partner = V + (HALVES == 2 ? ((wave & 1) ? -1 : 1) * WSTRIDE : 0) +
-                               lds_listed(CPL, HALVES) * SLOTS;
+                               lds_listed(CPL, HALVES, SPECIAL) * SLOTS;
     if constexpr (HALVES == 2) {
         PairBox *boxes = reinterpret_cast<PairBox *>(wave_base + (size_t)WPB * WSTRIDE);
         comm.lane = lane;
@@ -864,14 +880,14 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     if (lane < 32) prof_lds[64 + lane] = 0;
     int prof_slot = 31;
 #endif
-    WaveVecs<CPL, HALVES> W;
+    WaveVecs<CPL, HALVES, SPECIAL> W;
     W.lds = V;
     // (TWO: the wave index as a scalar, so that the region's base is an SGPR pair and every access is "scalar base +
     //  lane offset + immediate" -- with a per-lane base hipcc keeps one 64-bit VGPR address per vector and cell,
     //  ~170 registers of them, and spills those)
     W.spill = (__attribute__((address_space(1))) double *)A.wave_spill +
-              ((size_t)blockIdx.x * WPB + (TWO ? uniform_i(wave) : wave)) * (size_t)spill_doubles(CPL, HALVES);
-    if constexpr (TWO) W.bind(A.wave_spill + ((size_t)blockIdx.x * WPB + uniform_i(wave)) * (size_t)spill_doubles(CPL, HALVES));
+              ((size_t)blockIdx.x * WPB + (TWO ? uniform_i(wave) : wave)) * (size_t)spill_doubles(CPL, HALVES, SPECIAL);
+    if constexpr (TWO) W.bind(A.wave_spill + ((size_t)blockIdx.x * WPB + uniform_i(wave)) * (size_t)spill_doubles(CPL, HALVES, SPECIAL));
     change_D_init(ru, lane);
     const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
@@ -957,12 +973,12 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     // the row-start state in the global region for CPL 9-10 (+4 %).
     // (measured neutral at CPL = 5; with the split column: 40 % less scratch, 0.8 % slower; at two waves per SIMD every
     //  register counts: D = 101 +3 %, D = 192 +11 %)
-    constexpr bool DEEP = CPL >= 6 || CPL <= 3 || TWO;     // (CPL = 4, one wave per SIMD: -1 %)
+    constexpr bool DEEP = CPL >= 6 || CPL <= 3 || (TWO && (HC_TWO_PARTS & 8));     // (CPL = 4, one wave per SIMD: -1 %)
     // the row-start state out of registers: CPL 9-10 (with DEEP at CPL <= 3: D = 101 +1.6 %, D = 192 -9.5 %; at CPL = 8: -3 %).
     // At CPL 9-10 both are on since round 3 (+7.7 % / +3.5 % on the one-wave kernels; the combination round 2 saw
     // miscompiled belonged to a noise path that no longer exists -- DESIGN.md §5 "Deep columns";
     // test_one_wave_kernels_of_the_deepest_columns_keep_their_guards holds the two symptoms of that build against it).
-    constexpr bool DEEPY = CPL >= 9 || TWO;
+    constexpr bool DEEPY = CPL >= 9 || (TWO && (HC_TWO_PARTS & 16));
     int gs_keep[CPL], gp_keep[CPL], gn_keep[CPL];
     if (!DEEP) {
 #pragma unroll

@@ -352,7 +352,7 @@ LaunchCfg launch_cfg(hc_handle *h, unsigned grid)
 
 int launch_step(hc_handle *h, const StepArgs &A)
 {
-    const int wpb = wpb_of(h->cpl);
+    const int wpb = wpb_of(h->cpl, 1, h->use_special());
     HIP_TRY(hipMemsetAsync(h->counters.p + 63, 0, sizeof(unsigned long long), h->stream));
     if (h->use_pair()) {
         // split column: a workgroup runs two members at a time, two waves each
@@ -377,7 +377,7 @@ int launch_step(hc_handle *h, const StepArgs &A)
 
 int launch_rhs(hc_handle *h, const StepArgs &A, long long row, double *dydt, double *aux)
 {
-    const int wpb = wpb_of(h->cpl);
+    const int wpb = wpb_of(h->cpl, 1, h->use_special());
     if (h->use_pair() && !aux) {          // the split-column code path (the c | s | f view stays with the one-wave hook)
         StepArgs B = A;
         B.tab = h->tab_pair.p;
@@ -437,7 +437,7 @@ int fill_args(hc_handle *h, StepArgs &A)
         // chunks of one point's members for the multi-point scheduler: >= 8 chunks per workgroup when the ensemble
         // allows it, <= 32 members per wave (that bounds the idle time at a chunk's end to ~1.5 %) and never fewer
         // members than the workgroup has waves
-        const long long waves = wpb_of(h->cpl);     // (several points never run on the split-column kernel)
+        const long long waves = wpb_of(h->cpl, 1, h->use_special());     // (several points never run on the split-column kernel)
         long long chunk = h->chunk_members > 0 ? h->chunk_members : (h->n_members + 8LL * h->n_cu - 1) / (8LL * h->n_cu);
         chunk = std::max<long long>(waves, std::min<long long>(chunk, 32 * waves));
         chunk = std::min<long long>(chunk, A.members_per_point);
@@ -447,7 +447,8 @@ int fill_args(hc_handle *h, StepArgs &A)
     }
     {
         // deep columns: room for the per-wave vectors LDS cannot hold, for every wave of the persistent grid
-        const size_t per_wave = std::max((size_t)spill_doubles(h->cpl), (size_t)spill_doubles(PAIR_CPL, 2));
+        const size_t per_wave = std::max(std::max((size_t)spill_doubles(h->cpl, 1, true), (size_t)spill_doubles(h->cpl, 1, false)),
+                                         (size_t)spill_doubles(PAIR_CPL, 2));
         const size_t cnt = (size_t)h->n_cu * MAX_WAVES_PER_BLOCK * per_wave;
         if (h->wave_spill.ensure(cnt)) return HC_ERR_DEVICE;
         A.wave_spill = h->wave_spill.p;

@@ -36,7 +36,7 @@ def parse_report(text):
         if m:
             cur = out.setdefault(m.group(1), {})
             continue
-        m = re.search(r"remark: .*?\s{2,}([A-Za-z][A-Za-z \[\]/]+?): (\d+)", line)
+        m = re.search(r"remark:\s+([A-Za-z][A-Za-z \[\]/]+?): (\d+)", line)
         if m and cur is not None and m.group(1).strip() in FIELDS:
             cur[FIELDS[m.group(1).strip()]] = int(m.group(2))
     return out
