@@ -282,7 +282,7 @@ __device__ __forceinline__ double rsqrt_ge1(double x)
 // set of a 640-node column (hipcc 7.2: 1.5 KB of scratch per lane at 10 cells per lane); two waves hold it in two
 // register files with 0.2 KB.  What crosses the cut -- the stencil's edge values, every reduction, the
 // coupling of the two tridiagonal blocks -- goes through a mailbox in LDS: double-buffered payload, one sequence counter
-// per half (release store / acquire load at workgroup scope), no s_barrier (the other pair of the workgroup runs another
+// per half (volatile mailbox accesses between a workgroup-scope release fence and acquire fence), no s_barrier (the other pair of the workgroup runs another
 // member with its own control flow).  Both halves execute the same sequence of exchanges: every branch that contains
 // one is decided by values both halves hold identically.
 struct PairBox {
@@ -342,6 +342,12 @@ struct Comm<2> {
     {
         static_assert(N <= 8, "mailbox holds eight values per half");
         const unsigned p = k & 1u;
+        // Release: whatever this wave wrote to LDS before the exchange (row 0 of a group evaluation, its noise vector) is
+        // ordered before the sequence number that announces it.  The mailbox accesses themselves are volatile (kept in
+        // program order among themselves; LDS executes one wave's instructions in order); the fence is what keeps the
+        // compiler from moving a PLAIN LDS access of the surrounding code across them.  At workgroup scope on one CU
+        // it is an s_waitcnt, no cache operation.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) {
             volatile __attribute__((address_space(3))) double *out = box->data[p][half];
 #pragma unroll
@@ -372,6 +378,9 @@ struct Comm<2> {
                 break;
             }
         }
+        // Acquire: the partner's plain LDS writes that preceded its post (read later through row0[] / nz_partner) are not
+        // read before the poll that saw its sequence number
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
         for (int j = 0; j < N; j++) theirs[j] = uniform_d(v[j]);
         if (timed_out) {

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WPB *WAVE, 1) void rhs_kernel(const StepArgs A, lon
     Comm<1> comm;
     comm.half = 0;
 #ifdef HC_PROFILE
-    unsigned long long prof_dummy[64], prof_t = 0;     // rhs_eval's region stamps go nowhere in the hook
+    unsigned long long prof_dummy[96], prof_t = 0;     // rhs_eval's region stamps go nowhere in the hook (32 cycle sums + 64 entry counts)
     unsigned long long *prof_lds = prof_dummy;
     int prof_slot = 0;
 #endif

@@ -67,6 +67,7 @@ constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 enum { V_Y = 0, V_FP, V_FAC, V_D0, V_NZ = V_D0 + MAX_ORDER + 3, NVEC = V_NZ + 1, V_Y0 = NVEC,
        // TWO layout only: the predicted state / Jacobian base point, the Jacobian rows and FD steps, the factorisation
        V_YP, V_JL, V_JD, V_JU, V_HJ, V_FWF, V_FWB, V_FL, V_FU, V_FIB, NVEC_TWO };
+constexpr int TWO_GROUP_VECTORS = 16;    // f of each FD-Jacobian group evaluation (n_groups <= 16), behind the lane scalars
 constexpr int TWO_LANE_SCALARS = 14;     // per-lane scalars of the factorisation (wx, 1/B, al[6], ga[6]): [14][64] behind the vectors
 #ifdef HC_PROFILE
 constexpr int WAVE_SCRATCH = 256;   // + per wave: 32 cycle sums, 32 entry counts, 32 sub-region entry counts
@@ -92,9 +93,23 @@ constexpr int WAVE_SCRATCH = 160;
 #ifndef HC_TWO_MASK_GENERIC
 #define HC_TWO_MASK_GENERIC (1 << 4)           // generic exponents
 #endif
-__host__ __device__ constexpr bool two_of(int cpl, int halves = 1, bool special = true)
+// (development: the placement alone -- factorisation, Jacobian rows, predicted state in the wave's vectors instead of
+//  registers -- at ONE wave per SIMD: bits of HC_PLACED_MASK / HC_PLACED_MASK_GENERIC beyond the TWO masks)
+#ifndef HC_PLACED_MASK
+#define HC_PLACED_MASK 0
+#endif
+#ifndef HC_PLACED_MASK_GENERIC
+#define HC_PLACED_MASK_GENERIC 0
+#endif
+__host__ __device__ constexpr bool two_waves_of(int cpl, int halves = 1, bool special = true)
 {
     return halves == 1 && cpl >= 4 && (((special ? HC_TWO_MASK : HC_TWO_MASK_GENERIC) >> cpl) & 1);
+}
+// "TWO layout" = the hand placement; two waves per SIMD wherever two_waves_of says so
+__host__ __device__ constexpr bool two_of(int cpl, int halves = 1, bool special = true)
+{
+    return two_waves_of(cpl, halves, special) ||
+           (halves == 1 && cpl >= 4 && (((special ? HC_PLACED_MASK : HC_PLACED_MASK_GENERIC) >> cpl) & 1));
 }
 #ifdef HC_WAVES_PER_BLOCK
 __host__ __device__ constexpr int wpb_of(int, int = 1, bool = true) { return HC_WAVES_PER_BLOCK; }
@@ -102,7 +117,7 @@ constexpr int MAX_WAVES_PER_BLOCK = HC_WAVES_PER_BLOCK;
 #else
 __host__ __device__ constexpr int wpb_of(int cpl, int halves = 1, bool special = true)
 {
-    return (halves == 1 && (cpl <= 3 || two_of(cpl, halves, special))) ? 8 : 4;
+    return (halves == 1 && (cpl <= 3 || two_waves_of(cpl, halves, special))) ? 8 : 4;
 }
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 #endif
@@ -125,7 +140,8 @@ __host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1, bool spec
     const int wpb = wpb_of(cpl, halves, special);
     const int boxes = halves == 2 ? (wpb / 2) * (int)sizeof(PairBox) : 0;
     const int n = ((LDS_BYTES - tables - boxes) / wpb - WAVE_SCRATCH * 8) / (slots * 8);
-    return n < NVEC ? n : NVEC;
+    const int all = two_of(cpl, halves, special) ? (int)NVEC_TWO : (int)NVEC;
+    return n < all ? n : all;
 }
 // Room to spare (two cells per lane, eight waves per workgroup): the Jacobian's three rows and the FD steps -- per-lane
 // arrays that are live from the first group evaluation of a Jacobian to the factorisation, across every RHS evaluation in
@@ -153,7 +169,8 @@ __host__ __device__ constexpr int spill_vectors(int cpl, int halves = 1, bool sp
 // doubles of the global region one wave owns
 __host__ __device__ constexpr int spill_doubles(int cpl, int halves = 1, bool special = true)
 {
-    return spill_vectors(cpl, halves, special) * 64 * cpl + (two_of(cpl, halves, special) ? TWO_LANE_SCALARS * 64 : 0);
+    return spill_vectors(cpl, halves, special) * 64 * cpl +
+           (two_of(cpl, halves, special) ? TWO_LANE_SCALARS * 64 + TWO_GROUP_VECTORS * 64 * cpl : 0);
 }
 // rank of a vector in the keep-in-LDS order D0..D5, Y, FP, D6, FAC, D7 (, Y0: never in LDS)
 __host__ __device__ constexpr int vec_rank(int v)
@@ -168,6 +185,12 @@ __host__ __device__ constexpr int vec_rank(int v)
 // deep-column kernels already keep in the global region come last.
 __host__ __device__ constexpr int rank_two(int v)
 {
+#ifdef HC_TWO_RANK_ALT     // development: D[2] to the global region, one more vector of the factorisation in LDS
+    return v == V_NZ ? 0 : v == V_D0 ? 1 : v == V_D0 + 1 ? 2 : v == V_FWF ? 3 : v == V_FWB ? 4 : v == V_FL ? 5 :
+           v == V_FU ? 6 : v == V_FIB ? 7 : v == V_D0 + 2 ? 8 : v == V_JL ? 9 : v == V_JD ? 10 : v == V_JU ? 11 : v == V_HJ ? 12 :
+           v == V_YP ? 13 : v == V_D0 + 3 ? 14 : v == V_Y ? 15 : v == V_FP ? 16 : v == V_D0 + 4 ? 17 : v == V_FAC ? 18 :
+           v == V_D0 + 5 ? 19 : v == V_D0 + 6 ? 20 : v == V_D0 + 7 ? 21 : 22 /* V_Y0 */;
+#endif
     return v == V_NZ ? 0 : v == V_D0 ? 1 : v == V_D0 + 1 ? 2 : v == V_D0 + 2 ? 3 : v == V_FWF ? 4 : v == V_FWB ? 5 :
            v == V_FL ? 6 : v == V_FU ? 7 : v == V_FIB ? 8 : v == V_JL ? 9 : v == V_JD ? 10 : v == V_JU ? 11 : v == V_HJ ? 12 :
            v == V_YP ? 13 : v == V_D0 + 3 ? 14 : v == V_Y ? 15 : v == V_FP ? 16 : v == V_D0 + 4 ? 17 : v == V_FAC ? 18 :
@@ -181,6 +204,11 @@ struct WaveVecs {
     static constexpr int SLOTS = WAVE * CPL;
     static constexpr bool TWO = two_of(CPL, HALVES, SP);
     static constexpr int N_LDS = TWO ? lds_vectors(CPL, HALVES, SP) : lds_listed(CPL, HALVES, SP);
+    // the global region through a buffer resource (see gld / gst): the TWO layout and, since round 4, the deep columns
+#ifndef HC_RSRC_MIN_CPL
+#define HC_RSRC_MIN_CPL 8      // (measured: 6 cells per lane -5 %, 7 -1.4 %, 8 +5 %, 9 +11 %, 10 +42 %; digests unchanged)
+#endif
+    static constexpr bool RSRC = TWO || CPL >= HC_RSRC_MIN_CPL;
     double *lds;
     __attribute__((address_space(1))) double *spill;
     template <int VEC>
@@ -193,6 +221,7 @@ struct WaveVecs {
             static_assert(VEC <= V_Y0, "a vector of the TWO layout");
             if constexpr (VEC == V_NZ) return lds[N_LDS * SLOTS + slot];
             else if constexpr (vec_rank(VEC) < N_LDS) return lds[vec_rank(VEC) * SLOTS + slot];
+            else if constexpr (RSRC) return gld((vec_rank(VEC) - N_LDS) * SLOTS * 8, slot * 8);
             else return spill[(vec_rank(VEC) - N_LDS) * SLOTS + slot];
         }
     }
@@ -206,12 +235,18 @@ struct WaveVecs {
             static_assert(VEC <= V_Y0, "a vector of the TWO layout");
             if constexpr (VEC == V_NZ) lds[N_LDS * SLOTS + slot] = v;
             else if constexpr (vec_rank(VEC) < N_LDS) lds[vec_rank(VEC) * SLOTS + slot] = v;
+            else if constexpr (RSRC) gst((vec_rank(VEC) - N_LDS) * SLOTS * 8, slot * 8, v);
             else spill[(vec_rank(VEC) - N_LDS) * SLOTS + slot] = v;
         }
     }
     // TWO layout: per-lane scalar k of the factorisation
     __device__ __forceinline__ double ldS(int k, int lane) const { return gld((NVEC_TWO - N_LDS) * SLOTS * 8, (k * WAVE + lane) * 8); }
     __device__ __forceinline__ void stS(int k, int lane, double v) const { gst((NVEC_TWO - N_LDS) * SLOTS * 8, (k * WAVE + lane) * 8, v); }
+    // TWO layout: f of FD-Jacobian group evaluation g (stored whole, no read-modify-write of the Jacobian rows per group);
+    // the finalising phase gathers row entries by each lane's own group ids
+    static constexpr int FG_OFF = ((NVEC_TWO - N_LDS) * SLOTS + TWO_LANE_SCALARS * WAVE) * 8;
+    __device__ __forceinline__ void stG(int g_uniform, int slot, double v) const { gst(FG_OFF + g_uniform * (SLOTS * 8), slot * 8, v); }
+    __device__ __forceinline__ double ldG(int g_lane, int slot) const { return gld(FG_OFF, g_lane * (SLOTS * 8) + slot * 8); }
     // TWO layout: the wave's global region through a buffer resource -- scalar base + scalar vector offset + per-lane
     // byte offset + immediate, ONE address VGPR for every access (as plain global pointers hipcc keeps a 64-bit VGPR
     // address per vector and cell, ~170 registers, and spills them); out-of-range accesses are dropped by the hardware
@@ -744,6 +779,20 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #define HC_TWO_PARTS 31       // development: bit 0 factorisation, 1 Jacobian rows, 2 predicted state, 3 group ids, 4 row-start state
 #endif
     constexpr bool TWO_F = TWO && (HC_TWO_PARTS & 1), TWO_J = TWO && (HC_TWO_PARTS & 2), TWO_YP = TWO && (HC_TWO_PARTS & 4);
+    // Group evaluations of the FD Jacobian stored whole and the rows gathered once (WaveVecs::stG / ldG) instead of a
+    // read-modify-write of the three rows per group; the column parameters re-read from scalar memory at every RHS
+    // evaluation instead of ~60 SGPRs held (and spilled) across the phases.  Measured at 65 536 members
+    // (profiles/r04_two_layout_ab.txt, digests identical): 4 cells per lane +1.4 % with both (each alone: +0.2 % / -1.4 %);
+    // 5 cells per lane +3.3 % with the reload alone, -13 % with the gather (its per-lane offsets cost 100 B of scratch).
+#ifndef HC_TWO_JGATHER_MAX_CPL
+#define HC_TWO_JGATHER_MAX_CPL 4
+#endif
+    constexpr bool JG = TWO_J && CPL <= HC_TWO_JGATHER_MAX_CPL;
+#ifdef HC_TWO_NO_P_RELOAD
+    constexpr bool P_RELOAD = false;
+#else
+    constexpr bool P_RELOAD = TWO;
+#endif
     constexpr int WSTRIDE = (NVEC_K + NEXTRA) * SLOTS + WAVE_SCRATCH;     // doubles per wave
     static_assert(WPB == wpb_of(CPL, HALVES, SPECIAL), "the workgroup size the LDS layout was sized for");
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
@@ -886,8 +935,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     //  lane offset + immediate" -- with a per-lane base hipcc keeps one 64-bit VGPR address per vector and cell,
     //  ~170 registers of them, and spills those)
     W.spill = (__attribute__((address_space(1))) double *)A.wave_spill +
-              ((size_t)blockIdx.x * WPB + (TWO ? uniform_i(wave) : wave)) * (size_t)spill_doubles(CPL, HALVES, SPECIAL);
-    if constexpr (TWO) W.bind(A.wave_spill + ((size_t)blockIdx.x * WPB + uniform_i(wave)) * (size_t)spill_doubles(CPL, HALVES, SPECIAL));
+              ((size_t)blockIdx.x * WPB + (W.RSRC ? uniform_i(wave) : wave)) * (size_t)spill_doubles(CPL, HALVES, SPECIAL);
+    if constexpr (W.RSRC) W.bind(A.wave_spill + ((size_t)blockIdx.x * WPB + uniform_i(wave)) * (size_t)spill_doubles(CPL, HALVES, SPECIAL));
     change_D_init(ru, lane);
     const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
@@ -1169,7 +1218,29 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     }
                     if (phase < C_SUCCESS) {
                         HC_STAMP(16);   // RHS prologue (midpoints); rhs_eval stamps its own regions 24..29
-                        rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
+                        if constexpr (P_RELOAD) {
+                            // two waves per SIMD: the column parameters come from scalar memory at every evaluation (the
+                            // other wave covers the load) instead of ~60 SGPRs held -- and spilled -- across the phases
+                            const ColumnDev Pe = load_const(A.P + point);
+#ifdef HC_TWO_RND_LDS
+                            // ... and the scaled noise of the lane's cells is rebuilt from the LDS vector (2 reads + 1
+                            // multiplication per cell: the same product as at the attempt's start) instead of CPL register
+                            // pairs held across the phases
+                            double rnd_e[CPL];
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) {
+                                const int i = hb + lane * CPL + c;
+                                int idx = i >= 1 ? i - 1 : 0;
+                                idx = (i < D - 1) ? idx : 0;
+                                rnd_e[c] = tabw[T_NOISEC * TSLOTS + c * WAVE + lane] * W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL);
+                            }
+                            rhs_eval<CPL, SPECIAL, PREDICT>(Pe, R, tabw, lane, ycur, rnd_e, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
+#else
+                            rhs_eval<CPL, SPECIAL, PREDICT>(Pe, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
+#endif
+                        } else {
+                            rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
+                        }
                         HC_STAMP(17);   // after the RHS: dispatch to the phase block
                     }
                     // Phases run in topological order inside ONE loop iteration: a block that hands over to a
@@ -1376,7 +1447,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     if (phase == PH_JAC) {
                         HC_STAMP(PH_JAC);
                         HC_GROUPS();
-                        HC_J_LOAD();
+                        if constexpr (!JG) { HC_J_LOAD(); }
                         HC_YP_LOAD();
                         if (g < 0) {
                             HC_SUB(62);
@@ -1394,6 +1465,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                 }
                                 W.template st<V_FAC>(slot, fac);
                                 hj[c] = vnode[c] ? h : 1.0;
+                                if constexpr (JG) W.template st<V_HJ>(slot, hj[c]);
                             }
                             g = 0;
                         } else {
@@ -1401,15 +1473,23 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             // f holds fun(y + h * [group == g]); scatter into the three per-row slots
                             const double r0v = readlane_d(f[0], 0);
                             if (lane == 0 && comm.half == 0) row0[g] = r0v;
+                            if constexpr (JG) {
 #pragma unroll
-                            for (int c = 0; c < CPL; c++) {
-                                jl[c] = (gp[c] == g) ? f[c] : jl[c];
-                                jd[c] = (gs[c] == g) ? f[c] : jd[c];
-                                ju[c] = (gn[c] == g) ? f[c] : ju[c];
+                                for (int c = 0; c < CPL; c++) {
+                                    W.stG(g, c * WAVE + lane, f[c]);
+                                    hj[c] = W.template ld<V_HJ>(c * WAVE + lane);
+                                }
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < CPL; c++) {
+                                    jl[c] = (gp[c] == g) ? f[c] : jl[c];
+                                    jd[c] = (gs[c] == g) ? f[c] : jd[c];
+                                    ju[c] = (gn[c] == g) ? f[c] : ju[c];
+                                }
                             }
                             g++;
                         }
-                        HC_J_STORE();
+                        if constexpr (!JG) { HC_J_STORE(); }
                         HC_SUB_END();
                         if (g < A.n_groups) {
 #pragma unroll
@@ -1421,7 +1501,25 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     if (phase == C_JAC_FIN) {
                         HC_STAMP(C_JAC_FIN);
                         HC_GROUPS();
-                        HC_J_LOAD();
+                        if constexpr (JG) {
+                            if (jac_stage == 0) {
+                                // entry (row i, column j) = f_i of the evaluation that perturbed column j's group; entries
+                                // without a column (row 0's sub-diagonal, the last row's super-diagonal, padding) are masked
+                                // below by hasU / hasD / vnode
+#pragma unroll
+                                for (int c = 0; c < CPL; c++) {
+                                    const int s_ = c * WAVE + lane;
+                                    jl[c] = W.ldG(gp[c] < 0 ? 0 : gp[c], s_);
+                                    jd[c] = W.ldG(gs[c] < 0 ? 0 : gs[c], s_);
+                                    ju[c] = W.ldG(gn[c] < 0 ? 0 : gn[c], s_);
+                                    hj[c] = W.template ld<V_HJ>(s_);
+                                }
+                            } else {
+                                HC_J_LOAD();        // after the retry pass: the rows as it left them
+                            }
+                        } else {
+                            HC_J_LOAD();
+                        }
                         HC_YP_LOAD();
                         // _sparse_num_jac: per-column max |diff| (rows j-1, j, j+1), its scale, factor update,
                         // J = diff / h.  jac_stage 0 = first look, 1 = after the retry pass below.
@@ -1485,6 +1583,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             flags_lds[lane] = small_bits;
                             __builtin_amdgcn_wave_barrier();
                             if (lane == 0 && comm.half == 0) atomicAdd(&load_const(A.io).counters[0], 1ull);
+                            if constexpr (JG) { HC_J_STORE(); }      // the retry pass works on the rows in memory
                             jac_stage = 1;
                             g = __ffs(redo_mask) - 1;
 #pragma unroll
