@@ -33,7 +33,7 @@ REQUIRED_KEYS = ("Trees", "Well_No", "Output_Name", "IC_Filename",
                  "Hydrological_Model", "Hydraulic_Conductivity")
 
 
-def validateInputParametersFile(filename):
+def validateInputParametersFile(filename, quiet=False):
     """berkeley_hydro_main.py:13-61: key membership only, values are not validated here."""
     import json
     with open(filename, "r") as fh:
@@ -41,17 +41,26 @@ def validateInputParametersFile(filename):
     missing = [key for key in REQUIRED_KEYS if key not in settings]
     if missing:
         raise ValueError(f" Key: {missing[0]}, is not given.")
-    print(" Model parameters are given correctly.")
+    if not quiet:
+        print(" Model parameters are given correctly.")
     return settings
 
 
+def _speaks():
+    """One voice per run: the single process, or rank 0 of a multi-GPU run."""
+    import os
+    return int(os.environ.get("RANK", "0")) == 0
+
+
 def _read_parameters(params_file):
-    """The first half of berkeley_hydro_main.py:65-100: no file -> message + exit 1; a bad file -> its message + exit 1."""
+    """The first half of berkeley_hydro_main.py:65-100: no file -> message + exit 1; a bad file -> its message + exit 1.
+    (The ranks of a run this command started itself stay quiet: their parent has said it.)"""
+    import os
     if params_file is None:
         print(" The simulation can't run without input parameters.")
         sys.exit(1)
     try:
-        return validateInputParametersFile(Path(params_file))
+        return validateInputParametersFile(Path(params_file), quiet=("HYDROCOL_EXPECT_WORLD" in os.environ) or not _speaks())
     except ValueError as bad_key:
         print(bad_key)
         sys.exit(1)
@@ -89,7 +98,8 @@ def main(params_file=None, data_file=None, seed=None, device=0, gpus=None, _sett
             column_run.run()
             column_run.saveResults()
     except Exception as failure:  # noqa: BLE001 - the reference converts every failure to exit status 1
-        print(failure)
+        import os
+        print(failure if _speaks() else f" [rank {os.environ.get('RANK')}] {failure}")
         if ranks is not None:
             ranks.close()
         sys.exit(1)
@@ -231,10 +241,9 @@ def run_cli(argv=None):
             status = multigpu.launch_ranks(n_gpus, script, argv[1:])
             if status != 0:
                 sys.exit(1)
-            print(' Simulation completed.')
-            return
+            return                                  # (rank 0 has said " Simulation completed.")
         main(args.params, args.data, args.seed, args.device, args.gpus, _settings=settings)
-        if not multigpu.in_rank() or int(__import__("os").environ.get("RANK", "0")) == 0:
+        if _speaks():
             print(' Simulation completed.')
     else:
         sys.exit('Error: Not enough input parameters.')
