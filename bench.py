@@ -42,26 +42,31 @@ sys.path.insert(0, str(REPO))
 ROWS_PER_DAY = 48
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
-# Per-kernel constants from rocprofv3 PMC passes (profiles/README.md says which files), keyed by (depth nodes, cell model):
-#   hbm_bytes_per_member_launch: 2 x FETCH_SIZE (gfx950 counts half of the fetched bytes -- confirmed by a calibration
-#     dispatch that only loads and stores psi) + WRITE_SIZE, in bytes per member of a 48-row launch;
+# Per-kernel constants from rocprofv3 PMC passes: profiles/pmc_constants.json (written by tools/pmc_constants.py from the
+# counter CSVs it names), keyed by "<depth>/<cell model>" and valid for ONE device-code identity (hc_version()'s kernel
+# hash: kernel sources + compile flags + compiler).  A library built from other kernel code gets traffic: null -- counters
+# of another build are not this build's traffic.
+#   hbm_bytes_per_member_launch: 2 x FETCH_SIZE (gfx950 counts half of the fetched bytes -- MI355X_MICROARCH.md, confirmed
+#     by a calibration dispatch that only loads and stores psi) + WRITE_SIZE, in bytes per member of a 48-row launch;
 #   f64_flop_per_column_step: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 wave instructions x 64 lanes, FMA = 2 flop.
-PMC = {
-    (300, "special"): {"hbm_bytes_per_member_launch": (2 * 78574.5 + 178688.0) * 1024.0 / 65536.0,
-                       "f64_flop_per_column_step": (2019.5 + 3674.7 + 685.3 + 2 * 7846.5) * 64.0,
-                       "source": "profiles/r02_pmc_fetch_size.csv, r02_pmc_write_size.csv, r02_pmc_sq_f64_bench.csv"},
-    # generic-exponent kernel step_kernel<5, false, 4, false> (every sweep; n = 1.7 point, 65 536 members, day 1 of the 1-year
-    # forcing): FETCH_SIZE 83 130.3 KiB (calibration launch: 81 252.4 for 153 600 KiB loaded, the x2), WRITE_SIZE 190 243 KiB;
-    # fp64 wave instructions per column-step FMA 14 557 / MUL 5 141 / ADD 3 010 / transcendental 1 001
-    (300, "generic"): {"hbm_bytes_per_member_launch": (2 * 83130.3125 + 190243.0) * 1024.0 / 65536.0,
-                       "f64_flop_per_column_step": (5141.0 + 3010.4 + 1000.9 + 2 * 14557.1) * 64.0,
-                       "source": "profiles/r03_pmc_fetch_generic.csv, r03_pmc_write_generic.csv, r03_pmc_f64_generic.csv"},
-    # BASELINE config 2's kernel step_kernel<4, true, 4, false> (D = 200): FETCH_SIZE 54 457 KiB, WRITE_SIZE 134 149.6 KiB;
-    # FMA 7 091.5 / MUL 3 301.0 / ADD 1 907.7 / transcendental 634.8
-    (200, "special"): {"hbm_bytes_per_member_launch": (2 * 54457.0 + 134149.5625) * 1024.0 / 65536.0,
-                       "f64_flop_per_column_step": (3301.0 + 1907.7 + 634.8 + 2 * 7091.5) * 64.0,
-                       "source": "profiles/r03_pmc_fetch_cpl4.csv, r03_pmc_write_cpl4.csv, r03_pmc_f64_cpl4.csv"},
-}
+PMC_FILE = REPO / "profiles" / "pmc_constants.json"
+
+
+def pmc_constants(depth, model):
+    """(constants or None, why): the committed counter constants of this build's kernel for (depth, cell model)."""
+    try:
+        table = json.loads(PMC_FILE.read_text())
+    except (OSError, ValueError) as e:
+        return None, f"{PMC_FILE.name} unreadable ({e})"
+    from hydromodel_amd import _lib
+    have = _lib.kernel_hash()
+    if table.get("kernel_hash") != have:
+        return None, (f"{PMC_FILE.name} holds counters of kernel build {table.get('kernel_hash')}, the loaded library is "
+                      f"{have}: re-run tools/gpu_r4_pmc.sh + tools/pmc_constants.py")
+    rec = table.get("kernels", {}).get(f"{depth}/{model}")
+    if rec is None:
+        return None, f"no counter pass for depth {depth} / {model} in {PMC_FILE.name}"
+    return rec, rec["source"]
 
 
 def parse():
@@ -288,7 +293,29 @@ def run_sweep(args, rank, world, dev, dist):
     bytes_per_launch = float(n_local) * rows_per_launch * (16 * D + 16)
     launch_ms = sim.kernel_ms / max(sim.launches, 1)
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    pmc = PMC.get((D, "generic"))
+    pmc, pmc_why = pmc_constants(D, "generic")
+    # every rank's points into one [P][3][T] table (the product's own assembly: multigpu.assemble_points); its count row
+    # says that every point arrived complete
+    from hydromodel_amd import multigpu
+
+    class _Group:       # bench.py's process group behind the product's interface
+        rank, world, backend, dist = 0, 1, None, None
+
+        def __init__(self):
+            self.rank, self.world = rank, world
+            if world > 1:
+                self.dist, self.backend = dist, dist.get_backend()
+
+        def device_index(self):
+            return dev.index
+        allreduce_sum = multigpu.Ranks.allreduce_sum
+
+    t_asm = time.perf_counter()
+    whole, psi0_all, _ = multigpu.assemble_points(_Group(), P, {k: {"moments": m[j], "psi0": sim.psi0[j],
+                                                                 "spinup_iterations": int(sim.spinup_iters[j])}
+                                                             for j, k in enumerate(mine)}, forcing.dim_t, D)
+    assemble_s = time.perf_counter() - t_asm
+    counts_last = whole[:, 0, last]
     out = {
         "metric": "ensemble column-days/sec", "value": col_days / elapsed, "unit": "column-days/s",
         "n_gpus": world, "ranks": world, "backend": (dist.get_backend() if world > 1 else None),
@@ -300,12 +327,17 @@ def run_sweep(args, rank, world, dev, dist):
                                 f"spin-up per point; timed prefix = days {args.warmup + 1}..{args.warmup + args.steps}"),
                    "points": P, "members_per_point": M, "points_per_gpu": len(mine), "depth_nodes": D,
                    "rows_per_step": ROWS_PER_DAY, "noise": "philox4x32-10 in-kernel",
-                   "parallelism": f"whole points dealt round-robin x{world}, no collective"},
+                   "parallelism": f"whole points dealt round-robin x{world}, no data-path collective; one all-reduce "
+                                  f"assembles the [P][3][T] result"},
+        "sweep_assembled": {"points": int(P), "points_complete_last_row": int((counts_last == M).sum()),
+                            "members_per_point_last_row_min_max": [int(counts_last.min()), int(counts_last.max())],
+                            "table_shape": list(whole.shape), "initial_cond_shape": list(psi0_all.shape),
+                            "assemble_s": assemble_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": (pmc["hbm_bytes_per_member_launch"] * n_local
                                  if (pmc and abs(rows_per_launch - 48) < 1e-9) else None),
-                     "traffic_source": pmc["source"] if pmc else None,
+                     "traffic_source": pmc_why,
                      "kernel": "hc::step_kernel<5, generic exponents> (rank 0)", "launch_ms": launch_ms,
                      "launches": sim.launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "fp64-VALU/recurrence bound (SURVEY.md §8d); the costliest points set the pace"},
@@ -332,6 +364,10 @@ def run_sweep(args, rank, world, dev, dist):
         "sustained": None, "sustained_heavy": None, "cpu_baseline": None,
     }
     sim.close()
+    if int((counts_last == M).sum()) != P:
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(f"the assembled sweep table holds {int((counts_last == M).sum())} complete points of {P}")
     return out
 
 
@@ -406,7 +442,7 @@ def run_ensemble(args, rank, world, dev, dist):
     bytes_per_launch = float(N) * rows_per_launch * (16 * D + 16)
     launch_ms = sim.kernel_ms / max(sim.launches, 1)
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    pmc = PMC.get((D, "special"))
+    pmc, pmc_why = pmc_constants(D, "special")
 
     out = {
         "metric": "ensemble column-days/sec", "value": value, "unit": "column-days/s",
@@ -425,8 +461,7 @@ def run_ensemble(args, rank, world, dev, dist):
                      "traffic": (pmc["hbm_bytes_per_member_launch"] * N
                                  if (pmc and abs(rows_per_launch - 48) < 1e-9) else None),
                      "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same launch shape ({pmc['source']}), "
-                                        "scaled by members; psi stays in LDS for the 48 rows of a launch, so HBM sees "
-                                        "~1/45 of the algorithmic bytes") if pmc else None,
+                                        "scaled by members") if pmc else pmc_why,
                      "kernel": "hc::step_kernel", "launch_ms": launch_ms, "launches": sim.launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "path is fp64-VALU/recurrence bound (SURVEY.md §8d): ~24 RHS evaluations per "
@@ -443,6 +478,8 @@ def run_ensemble(args, rank, world, dev, dist):
     }
     sim.close()
     if members_seen != N * world:
+        if world > 1:
+            dist.destroy_process_group()
         raise SystemExit(f"the reduced moment table counts {members_seen} members, expected {N} x {world}")
     solo = rank == 0 and world == 1
     out["sustained"] = (sustained_leg(cols, forcing, psi0, args.sustained_members, args.sustained_days, args.seed,
@@ -476,6 +513,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.workload == "sweep" and world > args.points:
+        # (before any collective: a rank without a point would otherwise die alone and leave the others in a barrier)
+        raise SystemExit(f"bench.py: --gpus {world} ranks for --points {args.points}: a rank would have no parameter point")
     if args.probe_ranks:
         return probe_ranks(args, rank, world)
     import torch
