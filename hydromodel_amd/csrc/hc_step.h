@@ -85,13 +85,13 @@ constexpr int WAVE_SCRATCH = 160;
 // across an RHS evaluation; the factorisation, the Jacobian rows, the FD steps and the predicted state live in the wave's
 // LDS / global vectors and are loaded by the phase that uses them -- see WaveVecs and rank_two below.
 // Measured (profiles/r04_two_layout_ab.txt, state digests identical under -ffp-contract=on): default exponents 4 cells
-// per lane 1.25x, 5 cells 1.12x; generic exponents 4 cells 1.21x, 5 cells 0.92x (the generic cell model's working set
-// does not fit beside the Newton-hot vectors); 6 / 7 / 8 cells 0.84 / 0.77 / 0.49x (LDS holds 5 / 4 / 3 vectors a wave).
+// per lane 1.25x, 5 cells 1.12x; generic exponents 4 cells 1.21x, 5 cells 0.92x -- 1.08x once the column parameters are
+// re-read per evaluation (P_RELOAD below); 6 / 7 / 8 cells 0.84 / 0.77 / 0.49x (LDS holds 5 / 4 / 3 vectors a wave).
 #ifndef HC_TWO_MASK
 #define HC_TWO_MASK ((1 << 4) | (1 << 5))      // default exponents: bit per cells-per-lane count
 #endif
 #ifndef HC_TWO_MASK_GENERIC
-#define HC_TWO_MASK_GENERIC (1 << 4)           // generic exponents
+#define HC_TWO_MASK_GENERIC ((1 << 4) | (1 << 5))   // generic exponents
 #endif
 // (development: the placement alone -- factorisation, Jacobian rows, predicted state in the wave's vectors instead of
 //  registers -- at ONE wave per SIMD: bits of HC_PLACED_MASK / HC_PLACED_MASK_GENERIC beyond the TWO masks)

@@ -9,8 +9,11 @@ from pathlib import Path
 
 import numpy as np
 
+import os
+
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "_build" / "libhydro_oracle.so"
+# HYDRO_ORACLE_LIB: another build of the same source (`make -C oracle sanitize` points it at the ASan / UBSan library)
+LIB_PATH = Path(os.environ["HYDRO_ORACLE_LIB"]) if os.environ.get("HYDRO_ORACLE_LIB") else HERE / "_build" / "libhydro_oracle.so"
 
 VIEW_NODES, VIEW_TOP, VIEW_FIRST, VIEW_INTERIOR = 0, 1, 2, 3
 

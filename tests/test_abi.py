@@ -88,7 +88,7 @@ def test_every_kernel_unit_is_built_and_the_scheduler_table_names_real_units():
             assert group == ("-ffp-contract=on",) or (len(group) == 2 and group[0] == "-mllvm" and group[1].startswith("-amdgpu-"))
     # the units compiled as TWO-layout kernels are exactly the ones with source-determined contraction
     two = {k for k, groups in ge.UNIT_FLAGS.items() if ("-ffp-contract=on",) in groups}
-    assert two == {(4, 1), (5, 1), (4, 0)}
+    assert two == {(4, 1), (5, 1), (4, 0), (5, 0)}
     src = (ge.CSRC / "hc_inst.hip").read_text()
     assert "HC_INST_SPECIAL" in src and "HC_INST_PAIR" in src
 
