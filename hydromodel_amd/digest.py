@@ -39,7 +39,13 @@ def interp_linear(xk, yk, x_new):
         raise ValueError("A value in x_new is outside the interpolation range.")
     idx = np.searchsorted(xk, x_new).clip(1, xk.size - 1).astype(int)
     lo, hi = idx - 1, idx
-    slope = (yk[..., hi] - yk[..., lo]) / (xk[hi] - xk[lo])
+    # a zero-width knot interval (TreeRoots' linspace(0, ln dz, ln) has one when ln = 1: tree_roots.py:135) has no slope;
+    # scipy divides 0 / 0 there and multiplies the NaN by a zero offset only where nobody looks.  The value at such a
+    # knot is the knot's: slope 0.
+    dx = xk[hi] - xk[lo]
+    flat = dx == 0.0
+    slope = (yk[..., hi] - yk[..., lo]) / np.where(flat, 1.0, dx)
+    slope = np.where(flat, 0.0, slope)
     return slope * (x_new - xk[lo]) + yk[..., lo]
 
 

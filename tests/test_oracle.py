@@ -100,14 +100,22 @@ def test_rhs_matches_reference(well):
         assert rel_err(aux["tr_lf_int"], g[f"{name}_mid_tr_lf"]) < 1e-12, name
 
 
+# The ONE constructed state of G4 on which the oracle takes a step decision the other way than the reference's SciPy run
+# (an explicit allow-list with the expected statistics, not a blanket "at most one may flip"): the deepest well's (D = 581)
+# top_saturated, a stiff state of ~75 steps and 8 Jacobian refreshes.  Cause (tests/golden/README.md, "SuperLU"): the
+# oracle factors I - cJ by Gaussian elimination in natural order, SuperLU in its COLAMD order; the two solutions differ
+# in the last bits, and one of ~190 threshold tests of this row (Newton's convergence test at 3 % of tolerance) falls the
+# other way.  (well, state) -> (oracle statistics, reference statistics)
+KNOWN_STAT_FLIPS = {(581, "top_saturated"): ([199, 8, 35, 73], [195, 7, 32, 72])}
+
+
 @pytest.mark.parametrize("well", DEEP_WELLS)
 def test_single_row_solve_matches_reference(well):
-    """G4: every constructed state the reference solved (HLIFT at night aside).  Regular rows reproduce the reference's
-    solver statistics exactly; a stiff constructed state (> 100 RHS evaluations, ~75 steps, the Jacobian refreshed up to 15
-    times) may take a step decision the other way -- at most one per well does (top_saturated at the deepest well:
-    199/8/35/73 against 195/7/32/72) and then stays within the integrator's accuracy class."""
+    """G4: every constructed state the reference solved (HLIFT at night aside) reproduces the reference's solver statistics
+    (nfev, njev, nlu, steps) EXACTLY and its state to 1e-6 (regular rows) / 1e-2 (stiff rows, > 100 RHS evaluations) --
+    except the states named in KNOWN_STAT_FLIPS, which must show exactly the statistics recorded there and stay within the
+    integrator's accuracy class."""
     g = golden(f"g34_states_{well}.npz")
-    flipped = []
     for name in g["names"]:
         if name == "hlift_night":      # > 1000 RHS evaluations, chaotic; HLIFT is a "next" row (SURVEY §8f4)
             continue
@@ -118,14 +126,16 @@ def test_single_row_solve_matches_reference(well):
         ry = g[f"{name}_solve_y"]
         err = np.max(np.abs(y1 - ry) / (1.0 + np.abs(ry)))
         assert np.array_equal(n_after, g[f"{name}_solve_nrnd_after"])
-        if [st["nfev"], st["njev"], st["nlu"], st["nsteps"]] != ref_stats[0, :4].tolist():
-            assert ref_stats[0, 0] > 100 and err < 5e-2, (name, err, st, ref_stats)
-            flipped.append(name)
+        mine = [st["nfev"], st["njev"], st["nlu"], st["nsteps"]]
+        if (well, str(name)) in KNOWN_STAT_FLIPS:
+            want_mine, want_ref = KNOWN_STAT_FLIPS[(well, str(name))]
+            assert mine == want_mine and ref_stats[0, :4].tolist() == want_ref, (name, mine, ref_stats)
+            assert err < 5e-2, (name, err)
             continue
+        assert mine == ref_stats[0, :4].tolist(), (well, name, mine, ref_stats)
         tol = 1e-6 if st["nfev"] <= 100 else 1e-2
         assert err < tol, (name, err)
         assert len(ts) == len(g[f"{name}_solve_t"])
-    assert len(flipped) <= 1, flipped
 
 
 @pytest.mark.parametrize("well", [1, 200])
