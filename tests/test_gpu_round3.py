@@ -119,9 +119,12 @@ def test_whole_year_reference_oracle_and_gpu_side_by_side(gpu):
 
 def test_whole_year_equality_is_a_distribution_not_a_number(gpu):
     """How much of the year's water-table index an implementation shares with the reference is decided by where its
-    handful of give-up rows fall -- a last-bit matter.  Twelve GPU members and six oracle runs start from the
-    reference's initial condition perturbed by 1e-13 (relative) and consume the reference's own noise stream; every one of
-    them stays within one cell of the reference on every row, and their equality figures scatter over the same range.
+    handful of give-up rows fall -- a last-bit matter (the reference's OWN statistics on such rows move when nothing but
+    SuperLU's elimination order changes: tests/golden/superlu_order_check.py).  Twelve GPU members and twelve oracle runs
+    start from the reference's initial condition perturbed by 1e-13 (relative) and consume the reference's own noise
+    stream; every one of them stays within one cell of the reference on every row.  The acceptance is a TWO-SAMPLE one
+    (VERDICT r3 item 5b): the GPU's median equality figure must lie inside the oracle's own [min, max] +- 0.03 -- a kernel
+    that scatters differently from a faithful restatement of the algorithm fails, whatever the absolute numbers are.
     (One unperturbed GPU build measured 96.4 %, another -- an RHS with a different summation order, parity-green on
     every pinned row -- 75.3 %; the oracle itself 97.2 %.)"""
     from concurrent.futures import ThreadPoolExecutor
@@ -154,17 +157,19 @@ def test_whole_year_equality_is_a_distribution_not_a_number(gpu):
         d = np.abs(r["wtd_est"][1:] - ref_idx)
         return float((d == 0).mean()), int(d.max()), int((r["per_row"][:, 4] > 1).sum())
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
-        orc = list(ex.map(oracle_run, range(6)))
+    with ThreadPoolExecutor(max_workers=12) as ex:
+        orc = list(ex.map(oracle_run, range(N)))
     eq_orc = np.array([e for e, _, _ in orc])
     print(f"year-long equality with the reference under 1e-13 perturbations of the initial state: GPU (12 members) "
           f"min {eq_gpu.min():.1%} median {np.median(eq_gpu):.1%} max {eq_gpu.max():.1%}, retried rows "
-          f"{retried_gpu.min()}..{retried_gpu.max()}; oracle (6 runs) min {eq_orc.min():.1%} median {np.median(eq_orc):.1%} "
+          f"{retried_gpu.min()}..{retried_gpu.max()}; oracle ({N} runs) min {eq_orc.min():.1%} median {np.median(eq_orc):.1%} "
           f"max {eq_orc.max():.1%}, retried rows {min(r for _, _, r in orc)}..{max(r for _, _, r in orc)}; reference 14")
     assert d_gpu.max() <= 1 and max(m for _, m, _ in orc) <= 1            # never more than one cell from the reference
     assert (d_gpu[:1400] == 0).mean() > 0.98                              # the first month: before any give-up row
-    assert np.median(eq_gpu) >= 0.80 and eq_gpu.min() >= 0.60
-    assert np.median(eq_gpu) >= eq_orc.min() - 0.10                       # the GPU scatters like the oracle does
+    # two-sample: the GPU scatters like the oracle does
+    assert eq_orc.min() - 0.03 <= np.median(eq_gpu) <= eq_orc.max() + 0.03, (eq_gpu, eq_orc)
+    assert eq_gpu.min() >= eq_orc.min() - 0.15, (eq_gpu, eq_orc)          # ... and no single member falls out of that range
+    assert abs(int(np.median(retried_gpu)) - int(np.median([r for _, _, r in orc]))) <= 8   # give-up rows: same count class
 
 
 def _sweep_points(k=8):
