@@ -91,11 +91,16 @@ struct hc_handle {
     bool points_dirty = false;
     // split column (two waves per member, hc_device.h Comm<2>): columns of 513..640 nodes with one parameter point and
     // the root zone inside the upper half; its own slot layout of the tables (point 0 only)
-    bool pair_ok = false, no_split = false;      // HYDROCOL_SPLIT_COLUMN=0 keeps the one-wave kernels (A/B, cross-checks)
+    // HYDROCOL_SPLIT_COLUMN=0 keeps the one-wave kernels, =1 takes the split column wherever it applies (A/B, cross-checks).
+    // Default since round 4: the split column from 10 cells per lane on (D = 577..640).  With the deep kernels' global
+    // region behind a buffer resource the one-wave kernel at 9 cells per lane (D = 513..576) overtook it: 97.0 k against
+    // 95.7 k column-days/s, generic exponents 76.2 k against 68.6 k; at 10 cells per lane the split column still wins
+    // (95.8 k against 80.0 k, generic 68.7 k against 51.7 k) -- profiles/r04_depths.txt
+    bool pair_ok = false, no_split = false, force_split = false;
     std::vector<double> tab_pair_host;
     DevBuf<double> tab_pair;
     DevBuf<int> gtab_pair;
-    bool use_pair() const { return pair_ok && !no_split && n_points == 1; }
+    bool use_pair() const { return pair_ok && !no_split && n_points == 1 && (force_split || cpl >= 10); }
     int chunk_members = 0;       // HYDROCOL_CHUNK_MEMBERS (0: derived from the member count)
     DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
     DevBuf<double> wave_spill;   // per-wave vectors of deep columns that do not fit in LDS (hc_step.h WaveVecs)
@@ -558,7 +563,10 @@ int hc_create(int device_ordinal, hc_handle **out)
     if (rpl && atoi(rpl) > 0) h->rows_per_launch = atoi(rpl);
     if (const char *sg = getenv("HYDROCOL_STRICT_GUARD")) h->strict_guard = atoi(sg) != 0;
     if (const char *po = getenv("HYDROCOL_POINT_ORDER")) h->fixed_order = strcmp(po, "fixed") == 0;
-    if (const char *sc = getenv("HYDROCOL_SPLIT_COLUMN")) h->no_split = atoi(sc) == 0;
+    if (const char *sc = getenv("HYDROCOL_SPLIT_COLUMN")) {
+        h->no_split = atoi(sc) == 0;
+        h->force_split = atoi(sc) == 1;
+    }
     if (const char *mi = getenv("HYDROCOL_DEBUG_MAX_ITER"))    // test hook: forces abandoned attempts
         if (atoi(mi) > 0) h->max_phase_iterations = atoi(mi);
     const char *jr = getenv("HYDROCOL_DEBUG_JAC_REJECT");   // test hook: exercises num_jac's retry branch

@@ -402,8 +402,7 @@ def test_split_column_kernel_against_the_one_wave_kernel_and_the_oracle(gpu, dim
     fresh = rng.standard_normal((nf, N, cols.dim_d))
     res = {}
     for mode in ("split", "one-wave"):
-        if mode == "one-wave":
-            monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")
+        monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0" if mode == "one-wave" else "1")     # (1: also where it is not the default)
         st = gpu.EnsembleStepper(cols, forcing, N)
         st.set_state(y0)
         st.set_noise_host(base)
@@ -485,8 +484,7 @@ def test_per_member_spinup_on_the_split_column_kernel(gpu, monkeypatch):
     forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols)
     res = {}
     for mode in ("split", "one-wave"):
-        if mode == "one-wave":
-            monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")
+        monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0" if mode == "one-wave" else "1")     # (1: also where it is not the default)
         st = gpu.EnsembleStepper(cols, forcing, 5)
         st.set_noise_philox(13, 100)
         res[mode] = spinup_members_on_gpu(st, cols, forcing)
@@ -608,8 +606,7 @@ def test_rhs_at_the_deepest_reference_well_matches_the_reference(gpu, mode, monk
     `RichardsPDE.__call__`, through the RHS hook on the split-column path (two waves per member: edge states, water-table
     search, top flux and the cut's cell all cross the mailbox) and through the one-wave kernel of the same depth."""
     from helpers import rel_err
-    if mode == "one-wave":
-        monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")
+    monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0" if mode == "one-wave" else "1")
     _, cols, forcing = digest(581)
     g = golden("g34_states_581.npz")
     worst = 0.0
