@@ -967,7 +967,7 @@ def test_ensemble_mean_sigma_match_the_oracle_over_a_month(gpu):
 
 
 def test_attempt_that_chatters_on_a_discontinuity_is_abandoned_and_retried(gpu):
-    """A row found in the 262 144-member run (member 165 062, row 2 140 of the 1-year forcing, tools/guard_hunt.py):
+    """A row found in the 262 144-member run (member 165 062, row 2 140 of the 1-year forcing, tools/dev/guard_hunt.py):
     from this state the BDF step controller slides along a discontinuity of the RHS -- Newton only converges for
     h ~ 1e-11, the controller cycles halve / accept twice / x10 and time advances ~1e-11 per cycle.  SciPy's
     algorithm has no exit there; the CPU oracle does the same on most 1e-13 perturbations of this input.  Kernel and

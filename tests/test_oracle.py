@@ -267,7 +267,7 @@ def test_plugin_and_flag_variants_replay(fname, well, model, n_rows):
 
 
 def test_work_budget_ends_a_chattering_attempt():
-    """tests/golden/chatter_row_300.npz (found by tools/guard_hunt.py): most 1e-13 perturbations of this input send the
+    """tests/golden/chatter_row_300.npz (found by tools/dev/guard_hunt.py): most 1e-13 perturbations of this input send the
     BDF step controller into an endless halve / accept / x10 cycle at h ~ 1e-11 on a discontinuity of the RHS.  The
     oracle's work budget (HO_MAX_EVALS_PER_ATTEMPT, mirroring the kernel's) ends the attempt; the x0.8 retry gets through."""
     from hydromodel_amd.digest import ColumnTables, ForcingDigest

@@ -1,7 +1,7 @@
 """BASELINE config 2 (4 096 members x D=200, the whole 1-year forcing) at several launch lengths.
     python tools/cfg2_bench.py [rows_per_launch ...]   (default: 48 480 4380 17472)"""
 import json, os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import numpy as np
 from hydromodel_amd.digest import ColumnTables, ForcingDigest

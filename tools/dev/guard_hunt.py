@@ -1,7 +1,7 @@
 """Find attempts that exhaust the kernel's iteration budget at scale and replay one on the CPU oracle.
 python tools/guard_hunt.py [N] [days]"""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import numpy as np
 from hydromodel_amd.digest import ColumnTables, ForcingDigest

@@ -1,7 +1,7 @@
 """Replay the saved guard case (tools/guard_hunt.py) with explicit host noise on GPU and oracle.
 python tools/guard_replay.py [member] [row]"""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import numpy as np
 from hydromodel_amd.digest import ColumnTables, ForcingDigest

@@ -1,7 +1,7 @@
 """Throughput of the generic-exponent kernel (n != 2 and/or lambda != 1): python tools/prof_generic.py [n] [lam] [N] [D]
 (HC_LIB=<lib.so> selects a development build)"""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import numpy as np
 if os.environ.get("HC_LIB"):

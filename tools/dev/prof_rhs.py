@@ -1,6 +1,6 @@
 """rocprofv3 target: one RHS evaluation per member (night row then day row)."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 from helpers import digest, golden
 from hydromodel_amd.stepper import EnsembleStepper

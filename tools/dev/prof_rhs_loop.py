@@ -1,7 +1,7 @@
 """Diagnostic build (python tools/build_dev.py prof -DHC_PROFILE --cpl 5): time R back-to-back RHS evaluations per member at the
 step kernel's occupancy.  python tools/prof_rhs_loop.py <lib.so> [N] [reps] [row]"""
 import os, sys, pathlib, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 from hydromodel_amd import _lib
 _lib.LIB_PATH = pathlib.Path(sys.argv[1]).resolve()

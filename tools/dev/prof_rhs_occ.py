@@ -1,7 +1,7 @@
 """Diagnostic build: cost of one RHS evaluation per wave at different occupancies (LDS request per workgroup decides
 how many workgroups share a CU).  python tools/prof_rhs_occ.py <lib.so> <D> [N] [reps]"""
 import os, sys, pathlib, time, subprocess
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 if len(sys.argv) > 5:           # child: one measurement
     from hydromodel_amd import _lib

@@ -1,6 +1,6 @@
 """Small fixed workload for rocprofv3 counter passes: N members x D, one launch of R rows."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 import numpy as np
 from helpers import digest, golden

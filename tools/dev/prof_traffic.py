@@ -5,7 +5,7 @@ psi: exactly N*D*8 bytes each way in the kernel's real access pattern.
 Dispatch B: the benchmark launch shape, 48 rows.
 """
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 import numpy as np
 from helpers import digest, golden

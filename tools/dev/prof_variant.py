@@ -1,6 +1,6 @@
 """Time the step kernel of a development build: python tools/prof_variant.py <lib.so> [N]"""
 import os, sys, pathlib
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 from hydromodel_amd import _lib
 _lib.LIB_PATH = pathlib.Path(sys.argv[1]).resolve()

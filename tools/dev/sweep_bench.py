@@ -4,7 +4,7 @@ handle at a time and against one point at full occupancy.
     python tools/sweep_bench.py [P=64] [M=4096] [D=300] [days=2] [--no-alone]
 """
 import json, os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import numpy as np
 from hydromodel_amd.digest import ColumnTables, ForcingDigest

@@ -2,7 +2,7 @@
 tables, spin-up and a short ensemble run through the generic-exponent kernel; reports solver health per point.
 python tools/sweep_check.py [points_per_axis] [members] [days] [depth]"""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import copy
 import numpy as np
