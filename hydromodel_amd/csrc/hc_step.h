@@ -539,6 +539,20 @@ __device__ __forceinline__ void predict(const WV &W, int lane, double inv_alpha,
     }
 }
 
+// the predictor's y alone (the base point of a Jacobian refresh, TWO layout): the additions of predict<> in its order
+template <int CPL, int ORDER, class WV>
+__device__ __forceinline__ void predict_y(const WV &W, int lane, double (&yp)[CPL])
+{
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int slot = c * WAVE + lane;
+        double sy = W.ldD(0, slot);
+#pragma unroll
+        for (int k = 1; k <= ORDER; k++) sy += W.ldD(k, slot);
+        yp[c] = sy;
+    }
+}
+
 // ---- lane-partitioned tridiagonal factorisation of A = I - cc*J -------------------------
 // H = 2 (split column): each wave factorises ITS block of the matrix with the coupling across the cut removed -- the
 // upper half's last row loses its super-diagonal `couple` = c_last, the lower half's first row its sub-diagonal a_first --
@@ -783,7 +797,12 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     // read-modify-write of the three rows per group; the column parameters re-read from scalar memory at every RHS
     // evaluation instead of ~60 SGPRs held (and spilled) across the phases.  Measured at 65 536 members
     // (profiles/r04_two_layout_ab.txt, digests identical): 4 cells per lane +1.4 % with both (each alone: +0.2 % / -1.4 %);
-    // 5 cells per lane +3.3 % with the reload alone, -13 % with the gather (its per-lane offsets cost 100 B of scratch).
+    // 5 cells per lane +3.3 % with the reload alone, -13 % with the gather (its per-lane offsets cost 100 B of scratch;
+    // -15 % again after the traffic cuts below).
+    // Traffic of the global region (rocprofv3 FETCH / WRITE_SIZE: 188 + 221 KB per column-step at 5 cells per lane before):
+    // the FD steps move only where they change, the Jacobian's base point is recomputed from the difference rows instead
+    // of parked, the accepted state is stored when it can be the row's answer: +8.0 % at 5 cells, +3.2 % at 4, same bits.
+    // (Non-temporal stores for the write-mostly vectors: -3 %.)
 #ifndef HC_TWO_JGATHER_MAX_CPL
 #define HC_TWO_JGATHER_MAX_CPL 4
 #endif
@@ -860,6 +879,34 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             W.template st<V_HJ>(s_, hj[c]);                                \
         }                                                                  \
     }
+// TWO layout: the three rows without the FD steps (a Jacobian's steps change only where they are computed), and the steps alone;
+// with the rows in LDS (two cells per lane) these are the four-vector forms above
+#define HC_J_LOAD3()                                                       \
+    if constexpr (TWO_J) {                                                 \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
+            const int s_ = c * WAVE + lane;                                \
+            jl[c] = W.template ld<V_JL>(s_);                               \
+            jd[c] = W.template ld<V_JD>(s_);                               \
+            ju[c] = W.template ld<V_JU>(s_);                               \
+        }                                                                  \
+    } else {                                                               \
+        HC_J_LOAD();                                                       \
+    }
+#define HC_J_STORE3()                                                      \
+    if constexpr (TWO_J) {                                                 \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
+            const int s_ = c * WAVE + lane;                                \
+            W.template st<V_JL>(s_, jl[c]);                                \
+            W.template st<V_JD>(s_, jd[c]);                                \
+            W.template st<V_JU>(s_, ju[c]);                                \
+        }                                                                  \
+    } else {                                                               \
+        HC_J_STORE();                                                      \
+    }
+#define HC_HJ_LOAD()                                                                               \
+    if constexpr (TWO_J) {                                                                         \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) hj[c] = W.template ld<V_HJ>(c * WAVE + lane); \
+    }
 // TWO layout: the factorisation is written once per lu_factor and read by every Newton iteration (no register of it is
 // live across an RHS evaluation); the predicted state / Jacobian base point likewise
 #define HC_F_STORE()                                                       \
@@ -896,13 +943,23 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             F.ga[q] = W.ldS(8 + q, lane);                                  \
         }                                                                  \
     }
-#define HC_YP_STORE()                                                                              \
-    if constexpr (TWO_YP) {                                                                           \
-        _Pragma("unroll") for (int c = 0; c < CPL; c++) W.template st<V_YP>(c * WAVE + lane, yp[c]); \
-    }
+// TWO layout: the Jacobian's base point is not kept anywhere: it is D[0] for the first Jacobian of an attempt (y0) and the
+// predictor's sum of the difference rows -- unchanged since the step was entered -- for a refresh; the same additions in
+// the same order as predict<>, so the same bits (round 4: 15 KB of stores per column-step less than parking it)
+#define HC_YP_STORE()
 #define HC_YP_LOAD()                                                                               \
-    if constexpr (TWO_YP) {                                                                           \
-        _Pragma("unroll") for (int c = 0; c < CPL; c++) yp[c] = W.template ld<V_YP>(c * WAVE + lane); \
+    if constexpr (TWO_YP) {                                                                        \
+        if (jac_init) {                                                                            \
+            _Pragma("unroll") for (int c = 0; c < CPL; c++) yp[c] = W.ldD(0, c * WAVE + lane);       \
+        } else {                                                                                   \
+            switch (order) {                                                                       \
+                case 1: predict_y<CPL, 1>(W, lane, yp); break;                                     \
+                case 2: predict_y<CPL, 2>(W, lane, yp); break;                                     \
+                case 3: predict_y<CPL, 3>(W, lane, yp); break;                                     \
+                case 4: predict_y<CPL, 4>(W, lane, yp); break;                                     \
+                default: predict_y<CPL, 5>(W, lane, yp); break;                                    \
+            }                                                                                      \
+        }                                                                                          \
     }
     // f_new[group][row 0], <= 16 groups: row 0 belongs to the upper half, the lower half reads it there
     double *row0 = (HALVES == 2 && (wave & 1) ? ru - WSTRIDE : ru) + 108;
@@ -1447,7 +1504,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     if (phase == PH_JAC) {
                         HC_STAMP(PH_JAC);
                         HC_GROUPS();
-                        if constexpr (!JG) { HC_J_LOAD(); }
+                        if constexpr (!TWO_J) { HC_J_LOAD(); }          // (rows in LDS at two cells per lane)
                         HC_YP_LOAD();
                         if (g < 0) {
                             HC_SUB(62);
@@ -1465,7 +1522,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                 }
                                 W.template st<V_FAC>(slot, fac);
                                 hj[c] = vnode[c] ? h : 1.0;
-                                if constexpr (JG) W.template st<V_HJ>(slot, hj[c]);
+                                if constexpr (TWO_J) W.template st<V_HJ>(slot, hj[c]);
                             }
                             g = 0;
                         } else {
@@ -1473,6 +1530,10 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             // f holds fun(y + h * [group == g]); scatter into the three per-row slots
                             const double r0v = readlane_d(f[0], 0);
                             if (lane == 0 && comm.half == 0) row0[g] = r0v;
+                            if constexpr (TWO_J && !JG) {
+                                HC_J_LOAD3();
+                                HC_HJ_LOAD();
+                            }
                             if constexpr (JG) {
 #pragma unroll
                                 for (int c = 0; c < CPL; c++) {
@@ -1487,9 +1548,10 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                     ju[c] = (gn[c] == g) ? f[c] : ju[c];
                                 }
                             }
+                            if constexpr (TWO_J && !JG) { HC_J_STORE3(); }
                             g++;
                         }
-                        if constexpr (!JG) { HC_J_STORE(); }
+                        if constexpr (!TWO_J) { HC_J_STORE(); }
                         HC_SUB_END();
                         if (g < A.n_groups) {
 #pragma unroll
@@ -1601,7 +1663,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                 ju[c] = nju[c];
                                 if (vnode[c]) W.template st<V_FAC>(c * WAVE + lane, nfac[c]);
                             }
-                            HC_J_STORE();
+                            HC_J_STORE3();
                                 jac_stage = 0;
                             if (jac_init) {
                                 // rest of BDF.__init__: D[0] = y, D[1] = f0 * h_abs, order = 1
@@ -1652,8 +1714,13 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         t = t_new;
                         nsteps++;
                         double d_ord[CPL], d_ord2[CPL];          // updated D[order], D[order+2]
+                        // sol.y[:, -1] so far.  TWO layout: stored only when it can become the row's answer -- the step that
+                        // reaches tf, or any step of the fifth attempt (a failed earlier attempt restarts from y0 and
+                        // overwrites it): the same final bits, 5 of 6 global stores per row less
+                        if (!TWO || t == tf || attempts >= 5) {
 #pragma unroll
-                        for (int c = 0; c < CPL; c++) W.template st<V_Y>(c * WAVE + lane, ycur[c]);   // sol.y[:, -1] so far
+                            for (int c = 0; c < CPL; c++) W.template st<V_Y>(c * WAVE + lane, ycur[c]);
+                        }
                         switch (order) {
                             case 1: HC_SUB(41); accept_update<CPL, 1>(W, dd, lane, d_ord, d_ord2); break;
                             case 2: HC_SUB(42); accept_update<CPL, 2>(W, dd, lane, d_ord, d_ord2); break;
@@ -1753,7 +1820,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         HC_STAMP(C_NEWTON_BEGIN);
                         if (!have_lu) {
                             HC_STAMP(23);
-                            HC_J_LOAD();
+                            HC_J_LOAD3();
                             lu_factor<CPL>(F, jl, jd, ju, cc, lane, D, comm);
                             HC_F_STORE();
                             HC_STAMP(C_NEWTON_BEGIN);
