@@ -1531,10 +1531,18 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             const double r0v = readlane_d(f[0], 0);
                             if (lane == 0 && comm.half == 0) row0[g] = r0v;
                             if constexpr (TWO_J && !JG) {
-                                HC_J_LOAD3();
+                                // rows in memory: an entry changes in exactly the one group evaluation that perturbed its
+                                // column, so the scatter is three PREDICATED stores per cell -- no load, no rewrite of the
+                                // entries that stay (the read-modify-write of the register form keeps them too)
+#pragma unroll
+                                for (int c = 0; c < CPL; c++) {
+                                    const int s_ = c * WAVE + lane;
+                                    if (gp[c] == g) W.template st<V_JL>(s_, f[c]);
+                                    if (gs[c] == g) W.template st<V_JD>(s_, f[c]);
+                                    if (gn[c] == g) W.template st<V_JU>(s_, f[c]);
+                                }
                                 HC_HJ_LOAD();
-                            }
-                            if constexpr (JG) {
+                            } else if constexpr (JG) {
 #pragma unroll
                                 for (int c = 0; c < CPL; c++) {
                                     W.stG(g, c * WAVE + lane, f[c]);
@@ -1548,7 +1556,6 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                     ju[c] = (gn[c] == g) ? f[c] : ju[c];
                                 }
                             }
-                            if constexpr (TWO_J && !JG) { HC_J_STORE3(); }
                             g++;
                         }
                         if constexpr (!TWO_J) { HC_J_STORE(); }
