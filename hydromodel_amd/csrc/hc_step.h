@@ -820,7 +820,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #ifdef HC_SINGLE_POINT   // development builds: the scheduler of the multi-point mode compiled out (A/B timing)
     constexpr bool multi = false;
 #else
-    const bool multi = HALVES == 1 && A.n_points > 1;      // (the host never sends several points to the split-column kernel)
+    const bool multi = A.n_points > 1;      // (round 4: the split column serves several points too)
 #endif
     if (!multi)
         for (int k = threadIdx.x; k < NTAB * TSLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
@@ -1023,9 +1023,21 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         bool none_left = false;
         for (;;) {
             int m = 0;
-            if (lane == 0) m = __hip_atomic_fetch_add(const_cast<int *>(chunk_state), 1, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0 && comm.half == 0) m = __hip_atomic_fetch_add(const_cast<int *>(chunk_state), 1, __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             m = __builtin_amdgcn_readfirstlane(m);
+            if constexpr (HALVES == 2) {
+                // split column: the upper half draws, the lower half learns the draw; both then take the same path through
+                // the barriers below (the chunk bookkeeping only changes between barriers that both halves take part in)
+                const double mine[1] = {(double)m};
+                double theirs[1];
+                comm.xchg(mine, theirs);
+                m = comm.half == 0 ? m : (int)theirs[0];
+                if (comm.dead) {                 // (an exchange timed out: a bug, never the data -- leave; a terminated
+                    none_left = true;            //  wave no longer counts at the workgroup's barriers)
+                    break;
+                }
+            }
             // (LDS reads are per-lane values to the compiler: readfirstlane keeps the control flow scalar)
             if (m < __builtin_amdgcn_readfirstlane(chunk_state[1])) {
                 member = m;
@@ -1058,8 +1070,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             }
             const int pt = __builtin_amdgcn_readfirstlane(chunk_state[3]);
             if (pt != __builtin_amdgcn_readfirstlane(chunk_state[2])) {
-                const double *src = A.tab + (size_t)pt * (NTAB * SLOTS);
-                for (int k = threadIdx.x; k < NTAB * SLOTS; k += WPB * WAVE) tab[k] = src[k];
+                const double *src = A.tab + (size_t)pt * (NTAB * TSLOTS);
+                for (int k = threadIdx.x; k < NTAB * TSLOTS; k += WPB * WAVE) tab[k] = src[k];
                 __syncthreads();
                 if (threadIdx.x == 0) chunk_state[2] = pt;   // next read: after the first barrier of the next chunk change
             }
@@ -1937,7 +1949,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
         for (int c = 0; c < CPL; c++)
             if (vnode[c]) io.psi[member * D + hb + lane * CPL + c] = W.template ld<V_Y>(c * WAVE + lane);
         if (!A.host_noise && lane == 0 && comm.half == 0) io.nscale[member] = nscale;
-        if (multi && lane == 0) atomicAdd(&io.point_cost[point], (unsigned long long)cost_nfev);
+        if (multi && lane == 0 && comm.half == 0) atomicAdd(&io.point_cost[point], (unsigned long long)cost_nfev);
 #ifdef HC_PROFILE
         __builtin_amdgcn_wave_barrier();
         // split column: HC_PROFILE_HALF (default 0) says which half of the pairs reports -- the upper half is the critical path

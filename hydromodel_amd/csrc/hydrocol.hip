@@ -100,7 +100,7 @@ struct hc_handle {
     std::vector<double> tab_pair_host;
     DevBuf<double> tab_pair;
     DevBuf<int> gtab_pair;
-    bool use_pair() const { return pair_ok && !no_split && n_points == 1 && (force_split || cpl >= 10); }
+    bool use_pair() const { return pair_ok && !no_split && (force_split || cpl >= 10); }
     int chunk_members = 0;       // HYDROCOL_CHUNK_MEMBERS (0: derived from the member count)
     DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
     DevBuf<double> wave_spill;   // per-wave vectors of deep columns that do not fit in LDS (hc_step.h WaveVecs)
@@ -442,7 +442,8 @@ int fill_args(hc_handle *h, StepArgs &A)
         // chunks of one point's members for the multi-point scheduler: >= 8 chunks per workgroup when the ensemble
         // allows it, <= 32 members per wave (that bounds the idle time at a chunk's end to ~1.5 %) and never fewer
         // members than the workgroup has waves
-        const long long waves = wpb_of(h->cpl, 1, h->use_special());     // (several points never run on the split-column kernel)
+        // members a workgroup advances at once: its waves, or its pairs of waves on the split column
+        const long long waves = h->use_pair() ? wpb_of(PAIR_CPL, 2) / 2 : wpb_of(h->cpl, 1, h->use_special());
         long long chunk = h->chunk_members > 0 ? h->chunk_members : (h->n_members + 8LL * h->n_cu - 1) / (8LL * h->n_cu);
         chunk = std::max<long long>(waves, std::min<long long>(chunk, 32 * waves));
         chunk = std::min<long long>(chunk, A.members_per_point);
@@ -664,11 +665,19 @@ static int build_point(hc_handle *h, const hc_column_params *p, const double *no
     layout(h->cpl, 1, tab);
     for (double v : tab)
         if (!std::isfinite(v)) return fail(HC_ERR_ARG, "a column table entry is not finite");
+    // split column: 513..640 nodes, the root zone (cells 1..n_root_int) of EVERY point inside the upper half; each point
+    // brings its own tables in the two-halves layout (round 4: sweeps at these depths run on the split column too)
+    const bool pair_here = D > WAVE * 8 && D <= 2 * WAVE * PAIR_CPL && p->n_root_int <= WAVE * PAIR_CPL - 1;
     if (first) {
-        // split column: 513..640 nodes, the root zone (cells 1..n_root_int) inside the upper half
-        h->pair_ok = D > WAVE * 8 && D <= 2 * WAVE * PAIR_CPL && p->n_root_int <= WAVE * PAIR_CPL - 1;
+        h->pair_ok = pair_here;
         h->tab_pair_host.clear();
-        if (h->pair_ok) layout(PAIR_CPL, 2, h->tab_pair_host);
+    } else {
+        h->pair_ok = h->pair_ok && pair_here;
+    }
+    if (h->pair_ok) {
+        std::vector<double> tp;
+        layout(PAIR_CPL, 2, tp);
+        h->tab_pair_host.insert(h->tab_pair_host.end(), tp.begin(), tp.end());
     }
     const bool special = (p->model == HC_MODEL_VRETTAS_FUNG && p->n == 2.0 && p->m == 0.5 && p->lambda_exp == 1.0);
     if (first) {

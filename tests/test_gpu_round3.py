@@ -438,15 +438,57 @@ def test_split_column_kernel_against_the_one_wave_kernel_and_the_oracle(gpu, dim
     assert np.max(np.abs(a["diag"] - b["diag"])) < 5e-4      # later rows: the water table may cross a cell a row apart
 
 
-def test_deep_columns_fall_back_to_one_wave_where_the_split_kernel_does_not_apply(gpu, monkeypatch):
-    """Several parameter points in one handle (a sweep) keep the one-wave kernels at every depth; so does a column whose
-    root zone reaches into the lower half.  Both still run and agree with stand-alone handles."""
+def test_sweeps_deeper_than_576_nodes_run_on_the_split_column(gpu, monkeypatch):
+    """Round 4: several parameter points in one handle at 577..640 nodes take the split-column kernel
+    too -- every point brings its tables in the two-halves layout, the workgroup's chunk bookkeeping is drawn by the upper
+    half of a pair and learnt by the lower half through the mailbox.  Properties: (i) each point of a three-point sweep is
+    bit-equal -- states and moments -- to a stand-alone handle running that point with the same global member ids (also
+    the split column); (ii) the sweep agrees with the same sweep on the one-wave kernels (HYDROCOL_SPLIT_COLUMN=0) within
+    the chained-rows tier; (iii) per-point counts are complete.  At 513..576 nodes sweeps stay on the one-wave kernel of 9
+    cells per lane (the faster one there since round 4), as single points do."""
     from hydromodel_amd.digest import ColumnTables, ForcingDigest
     from hydromodel_amd.ensemble import SweepSimulation, check_sweep_points
     from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
     params = default_parameters()
-    pts = [{"Soil_Properties": {"a0": 0.012}}, {"Soil_Properties": {"n": 2.0}}]
-    cols_all = [ColumnTables(mp, synthetic_well(541)) for mp in check_sweep_points(params, pts)]
+    pts = [{"Soil_Properties": {"a0": 0.012}}, {"Soil_Properties": {"n": 2.0}}, {"Soil_Properties": {"n": 1.7, "psi_sat": -0.05}}]
+    for depth in (581, 640):
+        cols_all = [ColumnTables(mp, synthetic_well(depth)) for mp in check_sweep_points(params, pts)]
+        forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols_all[0])
+        psi0 = np.stack([c.z - 300.0 for c in cols_all])
+        M, rows = 7, 30                                         # ragged: 7 members per point on pairs of waves
+        big = SweepSimulation(cols_all, forcing, M, seed=2, psi0=psi0)
+        big.advance(rows)
+        y, mom = big.stepper.get_state(), big.moments()
+        big.close()
+        assert np.isfinite(y).all() and np.array_equal(mom[:, 0, 1:rows + 1], np.full((3, rows), M))
+        for k in range(3):
+            one = SweepSimulation([cols_all[k]], forcing, M, seed=2, first_point=k, psi0=psi0[k])
+            one.advance(rows)
+            assert np.array_equal(one.stepper.get_state(), y[k * M:(k + 1) * M]), (depth, k)
+            assert np.array_equal(one.moments()[0], mom[k]), (depth, k)
+            one.close()
+        monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")        # the same sweep on the one-wave kernels of 10 cells per lane
+        flat = SweepSimulation(cols_all, forcing, M, seed=2, psi0=psi0)
+        flat.advance(rows)
+        y1 = flat.stepper.get_state()
+        flat.close()
+        monkeypatch.delenv("HYDROCOL_SPLIT_COLUMN")
+        e = np.max(np.abs(y - y1) / (1.0 + np.abs(y1)))
+        print(f"[D={depth}] three-point sweep, split column vs one-wave kernels after {rows} rows: {e:.1e}")
+        assert e < 1e-3
+
+
+def test_deep_columns_fall_back_to_one_wave_where_the_split_kernel_does_not_apply(gpu, monkeypatch):
+    """A column whose root zone reaches into the lower half keeps the one-wave kernel (the split column's ET lives in the
+    upper half); so does a sweep in which ONE point has such roots.  Both still run; the sweep agrees with stand-alone
+    handles."""
+    from hydromodel_amd.digest import ColumnTables, ForcingDigest
+    from hydromodel_amd.ensemble import SweepSimulation, check_sweep_points
+    from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
+    params = default_parameters()
+    pts = [{"Soil_Properties": {"a0": 0.012}}, {"Soil_Properties": {"n": 2.0}, "Trees": {"Max_Root_Depth_cm": 2000.0}}]
+    cols_all = [ColumnTables(mp, synthetic_well(581)) for mp in check_sweep_points(params, pts)]
+    assert cols_all[0].n_root_int <= 319 < cols_all[1].n_root_int
     forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols_all[0])
     psi0 = np.stack([c.z - 300.0 for c in cols_all])
     big = SweepSimulation(cols_all, forcing, 6, seed=2, psi0=psi0)
@@ -454,9 +496,9 @@ def test_deep_columns_fall_back_to_one_wave_where_the_split_kernel_does_not_appl
     y = big.stepper.get_state()
     big.close()
     monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")            # a single point, one-wave kernel forced
-    one = SweepSimulation([cols_all[1]], forcing, 6, seed=2, first_point=1, psi0=psi0[1])
+    one = SweepSimulation([cols_all[0]], forcing, 6, seed=2, first_point=0, psi0=psi0[0])
     one.advance(10)
-    assert np.array_equal(one.stepper.get_state(), y[6:])
+    assert np.array_equal(one.stepper.get_state(), y[:6])
     one.close()
     monkeypatch.delenv("HYDROCOL_SPLIT_COLUMN")
     deep_roots = default_parameters()

@@ -16,12 +16,15 @@ from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-os.environ["HYDROCOL_SPLIT_COLUMN"] = "0"      # (a lone point deeper than 512 nodes would take the split-column kernel: other bits)
+# (round 4: sweeps and lone points take the same kernel at every depth -- the split column from 577 nodes on for both --
+#  so no kernel is forced here any more; FUZZ_ONE_WAVE=1 restores the one-wave kernels everywhere)
+if os.environ.get("FUZZ_ONE_WAVE"):
+    os.environ["HYDROCOL_SPLIT_COLUMN"] = "0"
 frame = synthetic_forcing_frame(1)
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
-    D = int(rng.choice([101, 121, 128, 150, 192, 193, 200, 241, 300, 321, 401, 470, 541]))
+    D = int(rng.choice([101, 121, 128, 150, 192, 193, 200, 241, 300, 321, 401, 470, 541, 581, 640]))
     P = int(rng.integers(2, 8))
     M = int(rng.choice([1, 2, 3, 7, 8, 9, 16, 17, 40, 130]))
     rows = int(rng.choice([5, 24, 50]))
