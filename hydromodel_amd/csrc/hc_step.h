@@ -86,9 +86,11 @@ constexpr int WAVE_SCRATCH = 160;
 // LDS / global vectors and are loaded by the phase that uses them -- see WaveVecs and rank_two below.
 // Measured (profiles/r04_two_layout_ab.txt, state digests identical under -ffp-contract=on): default exponents 4 cells
 // per lane 1.25x, 5 cells 1.12x; generic exponents 4 cells 1.21x, 5 cells 0.92x -- 1.08x once the column parameters are
-// re-read per evaluation (P_RELOAD below); 6 / 7 / 8 cells 0.84 / 0.77 / 0.49x (LDS holds 5 / 4 / 3 vectors a wave).
+// re-read per evaluation (P_RELOAD below); 6 / 7 / 8 cells 0.84 / 0.77 / 0.49x (LDS holds 5 / 4 / 3 vectors a wave) --
+// after the traffic cuts 6 cells 0.91x with the cell model in one batch of 5 + 1 and 1.065x in batches of 4 + 2
+// (-DHC_MODEL_BATCH=4 for that unit, __graft_entry__.UNIT_FLAGS), 7 cells 0.91x at best, generic 6 cells 0.97x.
 #ifndef HC_TWO_MASK
-#define HC_TWO_MASK ((1 << 4) | (1 << 5))      // default exponents: bit per cells-per-lane count
+#define HC_TWO_MASK ((1 << 4) | (1 << 5) | (1 << 6))      // default exponents: bit per cells-per-lane count
 #endif
 #ifndef HC_TWO_MASK_GENERIC
 #define HC_TWO_MASK_GENERIC ((1 << 4) | (1 << 5))   // generic exponents

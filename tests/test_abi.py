@@ -78,17 +78,19 @@ def test_product_never_imports_the_oracle():
 def test_every_kernel_unit_is_built_and_the_scheduler_table_names_real_units():
     """One translation unit per cells-per-lane count (2..10) and cell model, one for the split column; the per-unit
     settings (`UNIT_FLAGS`) may only name units that exist, as groups of command-line words: `-mllvm <option>` pairs
-    (tuning: droppable) or `-ffp-contract=on` (the TWO-layout units: part of the semantics, never dropped)."""
+    (tuning: droppable), `-ffp-contract=on` (the TWO-layout units: part of the semantics, never dropped) or the cell
+    model's batch size of one unit (same bits under `-ffp-contract=on`)."""
     import __graft_entry__ as ge
     assert tuple(ge.ALL_CPL) == tuple(range(2, 11))
     units = {(n, sp) for n in ge.ALL_CPL for sp in (0, 1)} | {"pair"}
     assert set(ge.UNIT_FLAGS) <= units
     for groups in ge.UNIT_FLAGS.values():
         for group in groups:
-            assert group == ("-ffp-contract=on",) or (len(group) == 2 and group[0] == "-mllvm" and group[1].startswith("-amdgpu-"))
+            assert group in (("-ffp-contract=on",), ("-DHC_MODEL_BATCH=4",)) or \
+                (len(group) == 2 and group[0] == "-mllvm" and group[1].startswith("-amdgpu-"))
     # the units compiled as TWO-layout kernels are exactly the ones with source-determined contraction
     two = {k for k, groups in ge.UNIT_FLAGS.items() if ("-ffp-contract=on",) in groups}
-    assert two == {(4, 1), (5, 1), (4, 0), (5, 0)}
+    assert two == {(4, 1), (5, 1), (6, 1), (4, 0), (5, 0)}
     src = (ge.CSRC / "hc_inst.hip").read_text()
     assert "HC_INST_SPECIAL" in src and "HC_INST_PAIR" in src
 
