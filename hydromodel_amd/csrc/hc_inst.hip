@@ -20,7 +20,8 @@ template <bool SPECIAL, bool PREDICT>
 hipError_t step_pair_one(const LaunchCfg &cfg, const StepArgs &A)
 {
     constexpr int WPB = wpb_of(PAIR_CPL, 2);
-    auto kern = step_kernel<PAIR_CPL, SPECIAL, WPB, PREDICT, 2>;
+    // (a handle with several parameter points takes the build with the chunk scheduler compiled in)
+    auto kern = A.n_points > 1 ? step_kernel<PAIR_CPL, SPECIAL, WPB, PREDICT, 2, true> : step_kernel<PAIR_CPL, SPECIAL, WPB, PREDICT, 2, false>;
     const size_t lds = step_lds_bytes(PAIR_CPL, WPB, 2);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);

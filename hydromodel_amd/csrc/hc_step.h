@@ -778,7 +778,9 @@ enum Phase {
 
 // HALVES = 2: a member's column is split over the waves 2p and 2p + 1 of the workgroup (Comm<2>, hc_device.h): SLOTS is
 // what ONE wave holds, the tables cover TSLOTS = 2 SLOTS slots, and each wave works on its half through `tabw` / `gtabw`.
-template <int CPL, bool SPECIAL, int WPB, bool PREDICT, int HALVES = 1>
+// PMULTI (split column only): the several-points scheduler compiled in.  Its mere presence cost the single-point split
+// kernel 3.4 % through register allocation (95.8 -> 92.5 k at D = 581), so a lone point keeps a build without it.
+template <int CPL, bool SPECIAL, int WPB, bool PREDICT, int HALVES = 1, bool PMULTI = false>
 __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArgs A)
 {
     constexpr int SLOTS = WAVE * CPL;
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #ifdef HC_SINGLE_POINT   // development builds: the scheduler of the multi-point mode compiled out (A/B timing)
     constexpr bool multi = false;
 #else
-    const bool multi = A.n_points > 1;      // (round 4: the split column serves several points too)
+    const bool multi = (HALVES == 1 || PMULTI) && A.n_points > 1;      // (round 4: the split column serves several points too)
 #endif
     if (!multi)
         for (int k = threadIdx.x; k < NTAB * TSLOTS; k += WPB * WAVE) tab[k] = A.tab[k];

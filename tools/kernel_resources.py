@@ -44,10 +44,11 @@ def parse_report(text):
 
 def short_name(mangled):
     """_ZN2hc11step_kernelILi5ELb1ELi4ELb0ELi1EEEvNS_8StepArgsE -> step<5,s,4,mon,1>"""
-    m = re.search(r"step_kernelILi(\d+)ELb([01])ELi(\d+)ELb([01])ELi(\d+)E", mangled)
+    m = re.search(r"step_kernelILi(\d+)ELb([01])ELi(\d+)ELb([01])ELi(\d+)ELb([01])E", mangled)
     if m:
-        cpl, sp, wpb, pr, hv = m.groups()
-        return f"step<{cpl},{'special' if sp == '1' else 'generic'},{wpb},{'predict' if pr == '1' else 'monitor'},{hv}>"
+        cpl, sp, wpb, pr, hv, pm = m.groups()
+        return (f"step<{cpl},{'special' if sp == '1' else 'generic'},{wpb},{'predict' if pr == '1' else 'monitor'},{hv}"
+                f"{',points' if pm == '1' else ''}>")
     return None
 
 
