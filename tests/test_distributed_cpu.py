@@ -84,3 +84,16 @@ def test_points_are_dealt_round_robin():
     assert sorted(sum(parts, [])) == list(range(512)) and all(len(p) == 64 for p in parts)
     assert parts[3][:3] == [3, 11, 19]
     assert deal_points(3, 5, 8) == []
+
+
+def test_bench_refuses_more_ranks_than_sweep_points():
+    """`--workload sweep --gpus N` with N > points would leave a rank without a point, dead before the first
+    barrier of the others -- refused up front, before any process group exists."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29998")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "sweep", "--points", "1"], cwd=repo, env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "a rank would have no parameter point" in p.stderr
