@@ -61,9 +61,10 @@ enum hc_status {
 
 #define HC_MODEL_VRETTAS_FUNG 0
 #define HC_MODEL_VAN_GENUCHTEN 1
-#define HC_MAX_DEPTH_NODES 640 /* 64 lanes x 10 cells; columns of 513..640 nodes with one parameter point and the root zone
-                                  above node 320 run on two cooperating wavefronts per member (64 x 5 cells each) unless
-                                  HYDROCOL_SPLIT_COLUMN=0 is in the environment at hc_create */
+#define HC_MAX_DEPTH_NODES 640 /* 64 lanes x 10 cells; columns of 577..640 nodes whose parameter points all keep the root
+                                  zone above node 320 run on two cooperating wavefronts per member (64 x 5 cells each),
+                                  single points and sweeps alike; HYDROCOL_SPLIT_COLUMN in the environment at hc_create:
+                                  0 keeps the one-wave kernels, 1 takes the two-wavefront kernel from 513 nodes on */
 
 /* One soil column geometry + parameter point (static during a run). */
 typedef struct {
