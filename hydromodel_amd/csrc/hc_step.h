@@ -65,8 +65,8 @@ constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 // global region instead of registers, shallower ones never use it.  (Parking the Jacobian rows and column steps there
 // as well was measured at D = 401 / 461 / 581: 7 % slower -- the compiler's own scratch placement does better.)
 enum { V_Y = 0, V_FP, V_FAC, V_D0, V_NZ = V_D0 + MAX_ORDER + 3, NVEC = V_NZ + 1, V_Y0 = NVEC,
-       // TWO layout only: the predicted state / Jacobian base point, the Jacobian rows and FD steps, the factorisation
-       V_YP, V_JL, V_JD, V_JU, V_HJ, V_FWF, V_FWB, V_FL, V_FU, V_FIB, NVEC_TWO };
+       // TWO layout only: the Jacobian rows and FD steps, the factorisation
+       V_JL, V_JD, V_JU, V_HJ, V_FWF, V_FWB, V_FL, V_FU, V_FIB, NVEC_TWO };
 constexpr int TWO_GROUP_VECTORS = 16;    // f of each FD-Jacobian group evaluation (n_groups <= 16), behind the lane scalars
 constexpr int TWO_LANE_SCALARS = 14;     // per-lane scalars of the factorisation (wx, 1/B, al[6], ga[6]): [14][64] behind the vectors
 #ifdef HC_PROFILE
@@ -80,7 +80,7 @@ constexpr int WAVE_SCRATCH = 160;
 // second wave fills the dependency stalls of the first.  From four cells per lane on the spill traffic outweighs that
 // (D = 256: 0.63x, D = 300: 0.59x), and three or four waves per SIMD lose at every depth (D = 128: 0.64x / 0.48x).
 // -DHC_WAVES_PER_BLOCK=n forces one count everywhere (A/B builds).
-// Round 4: two waves per SIMD at FOUR and FIVE cells per lane with hand-placed state ("TWO" layout, -DHC_TWO_MASK=<bit per
+// Round 4: two waves per SIMD at FOUR to SIX cells per lane with hand-placed state ("TWO" layout, -DHC_TWO_MASK=<bit per
 // cells-per-lane count>).  Nothing but the Newton-hot vectors (iterate, its noise, psi, d, 1/scale) stays in registers
 // across an RHS evaluation; the factorisation, the Jacobian rows, the FD steps and the predicted state live in the wave's
 // LDS / global vectors and are loaded by the phase that uses them -- see WaveVecs and rank_two below.
@@ -95,23 +95,11 @@ constexpr int WAVE_SCRATCH = 160;
 #ifndef HC_TWO_MASK_GENERIC
 #define HC_TWO_MASK_GENERIC ((1 << 4) | (1 << 5))   // generic exponents
 #endif
-// (development: the placement alone -- factorisation, Jacobian rows, predicted state in the wave's vectors instead of
-//  registers -- at ONE wave per SIMD: bits of HC_PLACED_MASK / HC_PLACED_MASK_GENERIC beyond the TWO masks)
-#ifndef HC_PLACED_MASK
-#define HC_PLACED_MASK 0
-#endif
-#ifndef HC_PLACED_MASK_GENERIC
-#define HC_PLACED_MASK_GENERIC 0
-#endif
-__host__ __device__ constexpr bool two_waves_of(int cpl, int halves = 1, bool special = true)
-{
-    return halves == 1 && cpl >= 4 && (((special ? HC_TWO_MASK : HC_TWO_MASK_GENERIC) >> cpl) & 1);
-}
-// "TWO layout" = the hand placement; two waves per SIMD wherever two_waves_of says so
+// "TWO layout" = the hand placement AND two waves per SIMD: the placement alone, at one wave per SIMD, loses at every depth
+// (0.74 - 0.93x: nothing hides the memory round trips; LAB_NOTES.md "Round 4")
 __host__ __device__ constexpr bool two_of(int cpl, int halves = 1, bool special = true)
 {
-    return two_waves_of(cpl, halves, special) ||
-           (halves == 1 && cpl >= 4 && (((special ? HC_PLACED_MASK : HC_PLACED_MASK_GENERIC) >> cpl) & 1));
+    return halves == 1 && cpl >= 4 && (((special ? HC_TWO_MASK : HC_TWO_MASK_GENERIC) >> cpl) & 1);
 }
 #ifdef HC_WAVES_PER_BLOCK
 __host__ __device__ constexpr int wpb_of(int, int = 1, bool = true) { return HC_WAVES_PER_BLOCK; }
@@ -119,7 +107,7 @@ constexpr int MAX_WAVES_PER_BLOCK = HC_WAVES_PER_BLOCK;
 #else
 __host__ __device__ constexpr int wpb_of(int cpl, int halves = 1, bool special = true)
 {
-    return (halves == 1 && (cpl <= 3 || two_waves_of(cpl, halves, special))) ? 8 : 4;
+    return (halves == 1 && (cpl <= 3 || two_of(cpl, halves, special))) ? 8 : 4;
 }
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 #endif
@@ -183,20 +171,14 @@ __host__ __device__ constexpr int vec_rank(int v)
 // TWO layout: keep-in-LDS order.  The noise vector (read across lanes), the difference rows an order-1 step touches
 // (a row's integration restarts at order 1 and rarely leaves it: 5.9 of 6.1 steps per row at D = 300), then what a
 // Newton iteration reads -- the factorisation in the order the solve consumes it, so that the parts that fall to the
-// global region are the ones needed last -- then the Jacobian rows, the FD steps, the predicted state; the vectors the
-// deep-column kernels already keep in the global region come last.
+// global region are the ones needed last -- then the Jacobian rows and the FD steps; the vectors the deep-column kernels
+// already keep in the global region come last.  (The predicted state / Jacobian base point has no vector: HC_YP_LOAD.)
 __host__ __device__ constexpr int rank_two(int v)
 {
-#ifdef HC_TWO_RANK_ALT     // development: D[2] to the global region, one more vector of the factorisation in LDS
-    return v == V_NZ ? 0 : v == V_D0 ? 1 : v == V_D0 + 1 ? 2 : v == V_FWF ? 3 : v == V_FWB ? 4 : v == V_FL ? 5 :
-           v == V_FU ? 6 : v == V_FIB ? 7 : v == V_D0 + 2 ? 8 : v == V_JL ? 9 : v == V_JD ? 10 : v == V_JU ? 11 : v == V_HJ ? 12 :
-           v == V_YP ? 13 : v == V_D0 + 3 ? 14 : v == V_Y ? 15 : v == V_FP ? 16 : v == V_D0 + 4 ? 17 : v == V_FAC ? 18 :
-           v == V_D0 + 5 ? 19 : v == V_D0 + 6 ? 20 : v == V_D0 + 7 ? 21 : 22 /* V_Y0 */;
-#endif
     return v == V_NZ ? 0 : v == V_D0 ? 1 : v == V_D0 + 1 ? 2 : v == V_D0 + 2 ? 3 : v == V_FWF ? 4 : v == V_FWB ? 5 :
            v == V_FL ? 6 : v == V_FU ? 7 : v == V_FIB ? 8 : v == V_JL ? 9 : v == V_JD ? 10 : v == V_JU ? 11 : v == V_HJ ? 12 :
-           v == V_YP ? 13 : v == V_D0 + 3 ? 14 : v == V_Y ? 15 : v == V_FP ? 16 : v == V_D0 + 4 ? 17 : v == V_FAC ? 18 :
-           v == V_D0 + 5 ? 19 : v == V_D0 + 6 ? 20 : v == V_D0 + 7 ? 21 : 22 /* V_Y0 */;
+           v == V_D0 + 3 ? 13 : v == V_Y ? 14 : v == V_FP ? 15 : v == V_D0 + 4 ? 16 : v == V_FAC ? 17 :
+           v == V_D0 + 5 ? 18 : v == V_D0 + 6 ? 19 : v == V_D0 + 7 ? 20 : 21 /* V_Y0 */;
 }
 
 // A wave's vectors: `lds` holds the first lds_listed(CPL) of the order above (then the noise vector, if it is in LDS),
@@ -1295,22 +1277,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             // two waves per SIMD: the column parameters come from scalar memory at every evaluation (the
                             // other wave covers the load) instead of ~60 SGPRs held -- and spilled -- across the phases
                             const ColumnDev Pe = load_const(A.P + point);
-#ifdef HC_TWO_RND_LDS
-                            // ... and the scaled noise of the lane's cells is rebuilt from the LDS vector (2 reads + 1
-                            // multiplication per cell: the same product as at the attempt's start) instead of CPL register
-                            // pairs held across the phases
-                            double rnd_e[CPL];
-#pragma unroll
-                            for (int c = 0; c < CPL; c++) {
-                                const int i = hb + lane * CPL + c;
-                                int idx = i >= 1 ? i - 1 : 0;
-                                idx = (i < D - 1) ? idx : 0;
-                                rnd_e[c] = tabw[T_NOISEC * TSLOTS + c * WAVE + lane] * W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL);
-                            }
-                            rhs_eval<CPL, SPECIAL, PREDICT>(Pe, R, tabw, lane, ycur, rnd_e, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
-#else
                             rhs_eval<CPL, SPECIAL, PREDICT>(Pe, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
-#endif
                         } else {
                             rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
                         }
