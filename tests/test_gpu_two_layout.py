@@ -1,0 +1,39 @@
+"""The TWO layout (two waves per SIMD with hand-placed state) changes WHERE the integrator's state lives, not one
+arithmetic operation: a build of the same source with the layout switched off (`-DHC_TWO_MASK=0`: the round-3 register
+layout, one wave per SIMD) must end in the same states to the bit.  Both are compiled with `-ffp-contract=on` (the unit's
+own flag), which is what makes the bits a property of the source rather than of the optimiser's view of it.
+
+VERDICT r3 item 1 "done means": A/B with identical state digests -- kept as a test, not only as a development record
+(`profiles/r04_two_layout_ab.txt`)."""
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _digests(lib, depths, members):
+    env = dict(os.environ, HC_PROF_MEMBERS=str(members))
+    p = subprocess.run([sys.executable, str(REPO / "tools" / "prof_depth.py"), str(lib), *map(str, depths)], cwd=REPO, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    out = dict((int(d), s) for d, s in re.findall(r"D=(\d+): .*? sha ([0-9a-f]{10})", p.stdout))
+    assert sorted(out) == sorted(depths), p.stdout
+    return out
+
+
+def test_one_wave_and_two_wave_builds_of_the_same_source_agree_to_the_bit(tmp_path):
+    import __graft_entry__ as ge
+    ge.build()
+    # the kernels of 5 cells per lane (D = 257..320: the bench's depth) with the TWO layout switched off
+    one_wave = ge.build_library(tmp_path / "lib_one_wave.so", cpls=(5,), obj_dir=tmp_path / "obj", force=True,
+                                defines=("-DHC_CPL_MASK=32", "-DHC_TWO_MASK=0", "-DHC_TWO_MASK_GENERIC=0"))
+    depths, members = [261, 300, 320], 3000          # 3 000 members: the 1-ulp difference of `fast` builds showed in ~1 member of 1 000
+    a = _digests(ge.CSRC / "libhydrocol.so", depths, members)
+    b = _digests(one_wave, depths, members)
+    assert a == b, (a, b)
