@@ -27,7 +27,6 @@ same algorithm) on every host core this process may use, for >= 30 s.
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -41,13 +40,19 @@ sys.path.insert(0, str(REPO))
 
 ROWS_PER_DAY = 48
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FABRIC_PEAK_GBPS = 8600.0       # ... its measured Infinity-Cache gather rate (38 MB table, uniformly random rows): what the
+                                # L2 <-> fabric counters of a cache-resident working set are priced against
+HBM_ACHIEVABLE_GBPS = 6290.0    # ... its measured streaming rate (float4 copy)
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
 # Per-kernel constants from rocprofv3 PMC passes: profiles/pmc_constants.json (written by tools/pmc_constants.py from the
 # counter CSVs it names), keyed by "<depth>/<cell model>" and valid for ONE device-code identity (hc_version()'s kernel
 # hash: kernel sources + compile flags + compiler).  A library built from other kernel code gets traffic: null -- counters
 # of another build are not this build's traffic.
-#   hbm_bytes_per_member_launch: 2 x FETCH_SIZE (gfx950 counts half of the fetched bytes -- MI355X_MICROARCH.md, confirmed
-#     by a calibration dispatch that only loads and stores psi) + WRITE_SIZE, in bytes per member of a 48-row launch;
+#   fabric_bytes_per_member_launch: 2 x FETCH_SIZE + WRITE_SIZE, in bytes per member of a 48-row launch.  These counters
+#     sit on the L2's memory side: they count Infinity-Cache hits and HBM accesses alike (MI355X_MICROARCH.md).  The factors
+#     are measured on known byte counts in the kernel's own access shapes (tools/pmc_calib.hip, profiles/r05_pmc_calib.txt):
+#     FETCH_SIZE reads 0.500 of the bytes of raw_buffer_load_b64 (512 B per wave instruction) and of the state's strided
+#     global loads, WRITE_SIZE 1.000 / 1.002 of the corresponding stores;
 #   f64_flop_per_column_step: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 wave instructions x 64 lanes, FMA = 2 flop.
 PMC_FILE = REPO / "profiles" / "pmc_constants.json"
 
@@ -62,7 +67,7 @@ def pmc_constants(depth, model):
     have = _lib.kernel_hash()
     if table.get("kernel_hash") != have:
         return None, (f"{PMC_FILE.name} holds counters of kernel build {table.get('kernel_hash')}, the loaded library is "
-                      f"{have}: re-run tools/gpu_r4_pmc.sh + tools/pmc_constants.py")
+                      f"{have}: re-run tools/gpu_r5_pmc.sh + tools/pmc_constants.py")
     rec = table.get("kernels", {}).get(f"{depth}/{model}")
     if rec is None:
         return None, f"no counter pass for depth {depth} / {model} in {PMC_FILE.name}"
@@ -85,11 +90,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="wall time of the CPU leg (BASELINE.md §3: >= 30 s)")
     ap.add_argument("--no-sustained", action="store_true")
-    ap.add_argument("--sustained-members", type=int, default=16384)
+    ap.add_argument("--sustained-members", type=int, default=65536)
     ap.add_argument("--sustained-days", type=int, default=365)
     ap.add_argument("--no-heavy", action="store_true")
-    ap.add_argument("--heavy-members", type=int, default=16384)
-    ap.add_argument("--heavy-days", type=int, default=364)
+    ap.add_argument("--heavy-members", type=int, default=65536)
+    ap.add_argument("--heavy-days", type=int, default=120)
+    ap.add_argument("--no-n1e6", action="store_true", help="skip the 1 048 576-member leg (north_star's N = 1e6 on one GPU)")
+    ap.add_argument("--n1e6-members", type=int, default=1048576)
+    ap.add_argument("--n1e6-days", type=int, default=3)
     ap.add_argument("--ic-file", default="", help="npz cache of the spun-up initial condition (written if missing)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
@@ -109,13 +117,12 @@ def launch_ranks(n_ranks):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes (one per
     GPU, torch.distributed.run on 127.0.0.1) and hand their output through.  Runs before this process has imported
     torch or touched the GPU; nothing is re-executed in place, nothing is retried.  Returns the launcher's exit code."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    # --standalone: the launcher's own c10d store picks a free port on 127.0.0.1 (no bind-close-reuse race)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n_ranks), str(Path(__file__).resolve())] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -210,6 +217,58 @@ def sustained_leg(cols, forcing, psi0, members, days, seed, device, label):
     return out
 
 
+def n1e6_leg(cols, forcing, psi0, members, days, seed, device):
+    """north_star's N = 1e6 on ONE GPU: `members` (default 1 048 576) x D members from the shared initial condition, one
+    warm-up day + `days` timed days (one 48-row launch each).  2.5 GB of state; the same kernel, a 4x longer launch."""
+    from hydromodel_amd.ensemble import EnsembleSimulation
+    sim = EnsembleSimulation(cols, forcing, members, seed=seed, device=device, psi0=psi0)
+    sim.advance(ROWS_PER_DAY)
+    sim.kernel_ms, sim.launches = 0.0, 0
+    t0 = time.perf_counter()
+    per_launch = []
+    for _ in range(days):
+        per_launch.append(sim.advance(ROWS_PER_DAY)["kernel_ms"])
+    wall = time.perf_counter() - t0
+    m = sim.moments()
+    last = sim.next_row - 1
+    out = {"value": members * days / wall, "unit": "column-days/s", "members": members, "days": days, "wall_s": wall,
+           "launch_ms": sim.kernel_ms / max(sim.launches, 1), "launch_ms_min": min(per_launch),
+           "launch_ms_max": max(per_launch), "launches": sim.launches,
+           "members_counted_last_row": int(m[0][last]),
+           "workload": f"{members} members x D={cols.dim_d}, days 2..{1 + days} of the same digest, one GPU"}
+    sim.close()
+    return out
+
+
+def roofline_object(bytes_per_launch, launch_ms, per_launch_ms, launches, pmc, pmc_why, members, rows_per_launch, kernel,
+                    note):
+    """The `roofline` entry of the JSON line.  `achieved` = algorithmic bytes / mean launch time against the HBM peak (the
+    contract's figure).  `traffic` = L2 <-> fabric bytes per launch by the committed counter passes of THIS kernel build
+    (null + the reason otherwise); `fabric` prices that traffic: it is Infinity-Cache and HBM traffic together -- the
+    counters cannot tell them apart -- so its peak is the guide's measured Infinity-Cache rate, with the HBM streaming
+    rate beside it."""
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    traffic = (pmc["fabric_bytes_per_member_launch"] * members
+               if (pmc and abs(rows_per_launch - 48) < 1e-9) else None)
+    fabric = None
+    if traffic is not None:
+        gbps = traffic / (launch_ms * 1e-3) / 1e9
+        fabric = {"achieved": gbps, "peak": FABRIC_PEAK_GBPS, "unit": "GB/s", "frac": gbps / FABRIC_PEAK_GBPS,
+                  "hbm_achievable": HBM_ACHIEVABLE_GBPS, "frac_of_hbm_achievable": gbps / HBM_ACHIEVABLE_GBPS,
+                  "traffic_over_algorithmic": traffic / bytes_per_launch,
+                  "what": "FETCH_SIZE x 2 + WRITE_SIZE: requests between the L2s and the fabric, Infinity-Cache hits "
+                          "included (the integrator's per-wave region cycling through the cache hierarchy, not psi "
+                          "re-read from HBM: profiles/r05_fabric_residency.txt)"}
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "fabric": fabric,
+            "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same launch shape ({pmc['source']}), "
+                               "scaled by members") if pmc else pmc_why,
+            "kernel": kernel, "launch_ms": launch_ms,
+            "launch_ms_min": min(per_launch_ms) if per_launch_ms else None,
+            "launch_ms_max": max(per_launch_ms) if per_launch_ms else None, "launches": launches,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "note": note}
+
+
 def probe_ranks(args, rank, world):
     """--probe-ranks: what did the launcher start?  Every rank joins the process group and adds a one."""
     import torch
@@ -273,8 +332,10 @@ def run_sweep(args, rank, world, dev, dist):
 
     sync()
     t0 = time.perf_counter()
+    per_launch_ms = []
     for _ in range(args.steps):
-        sim.advance(ROWS_PER_DAY)
+        step = sim.advance(ROWS_PER_DAY)
+        per_launch_ms.append(step["kernel_ms"] / max(step["launches"], 1))
     sync()
     elapsed = time.perf_counter() - t0
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -292,7 +353,6 @@ def run_sweep(args, rank, world, dev, dist):
     rows_per_launch = ROWS_PER_DAY * args.steps / max(sim.launches, 1)
     bytes_per_launch = float(n_local) * rows_per_launch * (16 * D + 16)
     launch_ms = sim.kernel_ms / max(sim.launches, 1)
-    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
     pmc, pmc_why = pmc_constants(D, "generic")
     # every rank's points into one [P][3][T] table (the product's own assembly: multigpu.assemble_points); its count row
     # says that every point arrived complete
@@ -332,15 +392,13 @@ def run_sweep(args, rank, world, dev, dist):
         "sweep_assembled": {"points": int(P), "points_complete_last_row": int((counts_last == M).sum()),
                             "members_per_point_last_row_min_max": [int(counts_last.min()), int(counts_last.max())],
                             "table_shape": list(whole.shape), "initial_cond_shape": list(psi0_all.shape),
-                            "assemble_s": assemble_s},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": (pmc["hbm_bytes_per_member_launch"] * n_local
-                                 if (pmc and abs(rows_per_launch - 48) < 1e-9) else None),
-                     "traffic_source": pmc_why,
-                     "kernel": "hc::step_kernel<5, generic exponents> (rank 0)", "launch_ms": launch_ms,
-                     "launches": sim.launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "note": "fp64-VALU/recurrence bound (SURVEY.md §8d); the costliest points set the pace"},
+                            "assemble_s": assemble_s,
+                            # identity of the assembled statistics: equal at any rank count (integer sums meeting zeros)
+                            "sha1": __import__("hashlib").sha1(np.ascontiguousarray(whole[:, :, :last + 1]).tobytes()).hexdigest()},
+        "roofline": roofline_object(bytes_per_launch, launch_ms, per_launch_ms, sim.launches, pmc, pmc_why, n_local,
+                                    rows_per_launch, "hc::step_kernel<5, generic exponents> (rank 0)",
+                                    "fp64-VALU/recurrence bound (SURVEY.md §8d); the costliest points set the pace; "
+                                    "counter constants are those of the n = 1.7 point"),
         "valu_f64": ({"achieved": (col_days / elapsed) * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world,
                       "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
                       "frac": (col_days / elapsed) * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world
@@ -418,8 +476,10 @@ def run_ensemble(args, rank, world, dev, dist):
 
     sync()
     t0 = time.perf_counter()
+    per_launch_ms = []
     for _ in range(args.steps):
-        sim.advance(ROWS_PER_DAY)          # hc_step_rows synchronises the library's stream
+        step = sim.advance(ROWS_PER_DAY)          # hc_step_rows synchronises the library's stream
+        per_launch_ms.append(step["kernel_ms"] / max(step["launches"], 1))
     sync()
     elapsed = time.perf_counter() - t0
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -441,7 +501,6 @@ def run_ensemble(args, rank, world, dev, dist):
     rows_per_launch = ROWS_PER_DAY * args.steps / max(sim.launches, 1)
     bytes_per_launch = float(N) * rows_per_launch * (16 * D + 16)
     launch_ms = sim.kernel_ms / max(sim.launches, 1)
-    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
     pmc, pmc_why = pmc_constants(D, "special")
 
     out = {
@@ -456,16 +515,11 @@ def run_ensemble(args, rank, world, dev, dist):
                                f"days {args.warmup + 1}..{args.warmup + args.steps}",
                    "members_per_gpu": N, "depth_nodes": D, "rows_per_step": ROWS_PER_DAY,
                    "noise": "philox4x32-10 in-kernel", "parallelism": f"members sharded x{world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": (pmc["hbm_bytes_per_member_launch"] * N
-                                 if (pmc and abs(rows_per_launch - 48) < 1e-9) else None),
-                     "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same launch shape ({pmc['source']}), "
-                                        "scaled by members") if pmc else pmc_why,
-                     "kernel": "hc::step_kernel", "launch_ms": launch_ms, "launches": sim.launches,
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "note": "path is fp64-VALU/recurrence bound (SURVEY.md §8d): ~24 RHS evaluations per "
-                             "column-step at ~10^2 flop per byte of state"},
+        "roofline": roofline_object(bytes_per_launch, launch_ms, per_launch_ms, sim.launches, pmc, pmc_why, N,
+                                    rows_per_launch, "hc::step_kernel",
+                                    "the path is fp64-VALU/recurrence bound (SURVEY.md §8d, `valu_f64` below): ~19 RHS "
+                                    "evaluations per column-step at ~10^2 flop per byte of state; psi stays on chip "
+                                    "for the 48 rows of a launch"),
         "valu_f64": ({"achieved": value * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world,
                       "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
                       "frac": value * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world
@@ -473,6 +527,8 @@ def run_ensemble(args, rank, world, dev, dist):
                       "source": "fp64 instruction mix per column-step from rocprofv3 PMC (profiles/README.md)"}
                      if pmc else None),
         "moments_allreduce_s": allreduce_s, "members_in_reduced_moments": members_seen,
+        # identity of the reduced statistics: equal at any rank count (integer sums keyed by global member ids)
+        "moments_sha1": __import__("hashlib").sha1(np.ascontiguousarray(np.asarray(moments)[:, :last_row + 1]).tobytes()).hexdigest(),
         "wtd_mean_cm_last_row": float(mean_cm[last_row]), "wtd_std_cm_last_row": float(std_cm[last_row]),
         "spinup_iterations": spin_iters,
     }
@@ -493,6 +549,8 @@ def run_ensemble(args, rank, world, dev, dist):
                                                local_rank, "the 1-year forcing")
     else:
         out["sustained_heavy"] = None
+    out["n1e6"] = (n1e6_leg(cols, forcing, psi0, args.n1e6_members, args.n1e6_days, args.seed, local_rank)
+                   if solo and not args.no_n1e6 else None)
     if solo and not args.no_cpu_baseline:
         threads = args.cpu_threads or host_cores()[0]
         out["cpu_baseline"] = cpu_baseline(cols, forcing, psi0, threads, args.cpu_seconds,

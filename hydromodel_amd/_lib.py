@@ -54,6 +54,7 @@ EXPORTS = {
     "hc_add_point": ([C.c_void_p, C.POINTER(ColumnParams), _dp, _dp], C.c_int),
     "hc_get_point_count": ([C.c_void_p], C.c_int),
     "hc_set_forcing": ([C.c_void_p, C.c_int64, _dp, _dp, _bp, _ip, _bp], C.c_int),
+    "hc_set_forcing_row": ([C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_uint8, C.c_int32], C.c_int),
     "hc_set_members": ([C.c_void_p, C.c_int64], C.c_int),
     "hc_set_state": ([C.c_void_p, _dp, C.c_int], C.c_int),
     "hc_get_state": ([C.c_void_p, _dp, C.c_int64, C.c_int64], C.c_int),

@@ -100,8 +100,12 @@ def main(params_file=None, data_file=None, seed=None, device=0, gpus=None, _sett
     except Exception as failure:  # noqa: BLE001 - the reference converts every failure to exit status 1
         import os
         print(failure if _speaks() else f" [rank {os.environ.get('RANK')}] {failure}")
-        if ranks is not None:
-            ranks.close()
+        # A failure may belong to this rank alone (its GPU, its shard): the peers are then inside, or heading for, the
+        # run's one all-reduce, and tearing the communicator down here can block on them.  Leave it alone and end the
+        # process with status 1 -- the launcher stops the other ranks and reports the failure.
+        sys.stdout.flush()
+        if ranks is not None and ranks.world > 1:
+            os._exit(1)
         sys.exit(1)
     ranks.close()
 
@@ -152,9 +156,14 @@ def _run_ensemble(params, water_data, output_name, ens, device, ranks):
     # the run's one collective: int64 (count, sum idx, sum idx^2) per row, exact and order-independent
     moments = ranks.allreduce_sum(np.asarray(sim.moments(), dtype=np.int64))
     mean_cm, std_cm = sim.wtd_mean_std(moments)
-    seen = int(np.max(moments[0][1:rows + 1])) if rows > 0 else n_members
-    if seen != n_members:
-        raise RuntimeError(f" Ensemble: the reduced moments hold {seen} members per row, expected {n_members}.")
+    # completeness, row by row: a solved row (its observation lies on the grid) must count every member of every shard,
+    # a skipped row nobody (simulation.py:582-588); a run whose rows are all skipped has nothing to check
+    expect = np.where(np.asarray(forcing.wtd_obs[1:rows + 1]) >= 0, n_members, 0).astype(np.int64)
+    got = np.asarray(moments[0][1:rows + 1], dtype=np.int64)
+    if not np.array_equal(got, expect):
+        bad = int(np.flatnonzero(got != expect)[0])
+        raise RuntimeError(f" Ensemble: the reduced moments hold {int(got[bad])} members on row {bad + 1}, expected "
+                           f"{int(expect[bad])} ({int((got != expect).sum())} rows differ).")
     psi0 = np.asarray(sim.psi0)
     extra = {}
     if psi0.ndim == 2 and ranks.world > 1:

@@ -840,9 +840,22 @@ __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const do
 }
 
 // deepest cell index with pred true, or -1: cells are (lane, c) -> index lane*CPL + c
-template <int CPL>
+// ONE_BALLOT (round 5, the two-waves-per-SIMD kernels): one ballot -- the deepest cell sits in the highest lane that has
+// any -- instead of one per cell slot and a scalar max over them.  The same index; +1.8 % at D = 300, +0.5 ... 0.7 % at
+// 241 / 361 where a second wave covers the extra VALU work, -0.5 ... -2.6 % on the one-wave kernels (D = 401 / 541), which
+// keep the scalar form.
+template <int CPL, bool ONE_BALLOT = false>
 __device__ __forceinline__ int deepest_true(const bool (&pred)[CPL])
 {
+    if constexpr (ONE_BALLOT) {
+        int bestc = -1;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) bestc = pred[c] ? c : bestc;
+        const unsigned long long m1 = __ballot(bestc >= 0);
+        if (!m1) return -1;
+        const int hi1 = 63 - __clzll((long long)m1);
+        return hi1 * CPL + __builtin_amdgcn_readlane(bestc, hi1);
+    }
     int best = -1;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
@@ -920,7 +933,7 @@ __device__ __forceinline__ double top_flux(const ColumnDev &P, const RowDev &R, 
 // 64 CPL x CommT::H slots apart.  With CommT = Comm<2> the wave holds one half of the column (see Comm above): the cut
 // costs two mailbox exchanges per evaluation -- the edge states at the start, and in the middle the water-table
 // candidates, the top flux (evaluated by the lower half, whose last slot is free) and the upper half's last cell.
-template <int CPL, bool SPECIAL, bool PREDICT, class CommT>
+template <int CPL, bool SPECIAL, bool PREDICT, bool ONE_BALLOT = false, class CommT>
 __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, const double *tab,
                                          int lane, const double (&y)[CPL], const double (&rnd)[CPL],
                                          double (&f)[CPL], double *aux, double &diag_tr, double &diag_lf, CommT &comm HC_RHS_PROF_PARAM)
@@ -1153,7 +1166,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             const int i = hb + lane * CPL + c;
             unsat0[c] = P.flag_lf && (i >= 1) && (i <= D - 2) && !(ym[c] >= P.psi_sat);
         }
-        const int j0 = deepest_true<CPL>(unsat0);
+        const int j0 = deepest_true<CPL, ONE_BALLOT>(unsat0);
         jstar_mine = j0 < 0 ? -1 : hb + j0;
         const double mine[5] = {(double)jstar_mine, comm.half == 0 ? readlane_d(Cc[CPL - 1], WAVE - 1) : pl,
                                 readlane_d(fl[CPL - 1], WAVE - 1), readlane_d(sk[CPL - 1], WAVE - 1),
@@ -1182,7 +1195,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                 const int i = hb + lane * CPL + c;
                 unsat[c] = (i >= 1) && (i <= D - 2) && !(ym[c] >= P.psi_sat);
             }
-            jstar = deepest_true<CPL>(unsat);
+            jstar = deepest_true<CPL, ONE_BALLOT>(unsat);
         }
         int wtd_est = jstar < 0 ? 0 : jstar;                  // p* + 1
         wtd_est = wtd_est < k - 1 ? wtd_est : k - 1;

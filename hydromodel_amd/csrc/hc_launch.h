@@ -22,7 +22,7 @@ inline size_t step_lds_bytes(int cpl, int wpb, int halves = 1, bool special = tr
 {
     const size_t slots = (size_t)WAVE * cpl;
     return (NTAB * slots * 8 + 4 * slots * 1) * halves +
-           (size_t)wpb * ((size_t)(lds_vectors(cpl, halves, special) + lds_extra(cpl, halves, special)) * slots + WAVE_SCRATCH) * 8 +
+           (size_t)wpb * ((size_t)lds_wave_doubles(cpl, halves, special) + WAVE_SCRATCH) * 8 +
            (halves == 2 ? (size_t)(wpb / 2) * sizeof(PairBox) : 0);
 }
 inline size_t rhs_lds_bytes(int cpl, int wpb)

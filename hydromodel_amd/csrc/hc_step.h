@@ -66,9 +66,9 @@ constexpr double NUM_JAC_MIN_FACTOR = 2.220446049250313e-13;
 // as well was measured at D = 401 / 461 / 581: 7 % slower -- the compiler's own scratch placement does better.)
 enum { V_Y = 0, V_FP, V_FAC, V_D0, V_NZ = V_D0 + MAX_ORDER + 3, NVEC = V_NZ + 1, V_Y0 = NVEC,
        // TWO layout only: the Jacobian rows and FD steps, the factorisation
-       V_JL, V_JD, V_JU, V_HJ, V_FWF, V_FWB, V_FL, V_FU, V_FIB, NVEC_TWO };
+       V_JL, V_JD, V_JU, V_HJ, NVEC_TWO };
 constexpr int TWO_GROUP_VECTORS = 16;    // f of each FD-Jacobian group evaluation (n_groups <= 16), behind the lane scalars
-constexpr int TWO_LANE_SCALARS = 14;     // per-lane scalars of the factorisation (wx, 1/B, al[6], ga[6]): [14][64] behind the vectors
+constexpr int TWO_LANE_SCALARS = 14;     // per-lane scalars of the factorisation (wx, 1/B, al[6], ga[6])
 #ifdef HC_PROFILE
 constexpr int WAVE_SCRATCH = 256;   // + per wave: 32 cycle sums, 32 entry counts, 32 sub-region entry counts
 #else
@@ -93,12 +93,18 @@ constexpr int WAVE_SCRATCH = 160;
 #define HC_TWO_MASK ((1 << 4) | (1 << 5) | (1 << 6))      // default exponents: bit per cells-per-lane count
 #endif
 #ifndef HC_TWO_MASK_GENERIC
-#define HC_TWO_MASK_GENERIC ((1 << 4) | (1 << 5))   // generic exponents
+#define HC_TWO_MASK_GENERIC ((1 << 4) | (1 << 5) | (1 << 6))   // generic exponents (6 cells: 0.97x in round 4, 1.034x with round 5's placement)
 #endif
 // "TWO layout" = the hand placement AND two waves per SIMD: the placement alone, at one wave per SIMD, loses at every depth
 // (0.74 - 0.93x: nothing hides the memory round trips; LAB_NOTES.md "Round 4")
+// Round 5: the split column (halves == 2, 5 cells per lane and half) takes the TWO layout too -- its halves are exactly the
+// shape where the layout pays -- i.e. FOUR member pairs per CU instead of two (-DHC_TWO_PAIR=0: the round-4 kernel).
+#ifndef HC_TWO_PAIR
+#define HC_TWO_PAIR 1
+#endif
 __host__ __device__ constexpr bool two_of(int cpl, int halves = 1, bool special = true)
 {
+    if (halves == 2) return HC_TWO_PAIR && cpl == 5;
     return halves == 1 && cpl >= 4 && (((special ? HC_TWO_MASK : HC_TWO_MASK_GENERIC) >> cpl) & 1);
 }
 #ifdef HC_WAVES_PER_BLOCK
@@ -107,7 +113,7 @@ constexpr int MAX_WAVES_PER_BLOCK = HC_WAVES_PER_BLOCK;
 #else
 __host__ __device__ constexpr int wpb_of(int cpl, int halves = 1, bool special = true)
 {
-    return (halves == 1 && (cpl <= 3 || two_of(cpl, halves, special))) ? 8 : 4;
+    return ((halves == 1 && cpl <= 3) || two_of(cpl, halves, special)) ? 8 : 4;
 }
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 #endif
@@ -123,16 +129,37 @@ constexpr int LDS_BYTES = 160 * 1024;
 // faster at every depth -- D = 401 +3 %, 541 +6 %, 581 +8 % -- and removes a second code path.)
 // `halves` = 2: a column split over two waves (hc_device.h, Comm<2>) -- each wave holds 64 cpl nodes, the shared tables
 // cover both halves, and the workgroup's two mailboxes sit behind the waves' vectors.
-__host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1, bool special = true)   // how many of the twelve fit
+// bytes of LDS one wave has for its vectors (next to the workgroup's tables, the pair mailboxes and the wave's scratch)
+__host__ __device__ constexpr int lds_wave_bytes(int cpl, int halves = 1, bool special = true)
 {
     const int slots = 64 * cpl;
     const int tables = (NTAB * slots * 8 + 4 * slots) * halves;
     const int wpb = wpb_of(cpl, halves, special);
     const int boxes = halves == 2 ? (wpb / 2) * (int)sizeof(PairBox) : 0;
-    const int n = ((LDS_BYTES - tables - boxes) / wpb - WAVE_SCRATCH * 8) / (slots * 8);
-    const int all = two_of(cpl, halves, special) ? (int)NVEC_TWO : (int)NVEC;
-    return n < all ? n : all;
+    return (LDS_BYTES - tables - boxes) / wpb - WAVE_SCRATCH * 8;
 }
+// TWO layout (round 5): LDS holds the three difference rows an order-1 step touches, D[0..2], and behind them as many
+// LANE-SLOTS (64 doubles) of the factorisation as fit -- the factorisation is 5 cpl + 8 lane-slots (the entries a solve
+// reads: wf of cells 1.., wb of cells ..cpl-3, l / u / 1/b of cells ..cpl-2, and the 14 per-lane scalars of the cyclic
+// reduction), placed slot by slot instead of vector by vector so that no LDS is left over: 16 of 33 at 5 cells per lane
+// (round 4: two vectors = 7 useful slots), 20 of 28 at 4, 12 of 38 at 6.
+constexpr int TWO_LDS_ROWS = 3;
+// (split column: + the block's answer to a unit load at the cut, sp[cpl], and one slot for the five wave-uniform
+//  coupling scalars, one per lane 0..4)
+__host__ __device__ constexpr int two_f_slots(int cpl, int halves = 1) { return 5 * cpl + 8 + (halves == 2 ? cpl + 1 : 0); }
+__host__ __device__ constexpr int two_f_lds(int cpl, int halves = 1, bool special = true)
+{
+    const int n = (lds_wave_bytes(cpl, halves, special) - TWO_LDS_ROWS * 64 * cpl * 8) / (64 * 8);
+    return n < 0 ? 0 : (n < two_f_slots(cpl, halves) ? n : two_f_slots(cpl, halves));
+}
+__host__ __device__ constexpr int lds_vectors(int cpl, int halves = 1, bool special = true)   // how many of the twelve fit
+{
+    if (two_of(cpl, halves, special)) return TWO_LDS_ROWS;
+    const int n = lds_wave_bytes(cpl, halves, special) / (64 * cpl * 8);
+    return n < (int)NVEC ? n : (int)NVEC;
+}
+// doubles of LDS per wave ahead of its scratch area
+__host__ __device__ constexpr int lds_wave_doubles(int cpl, int halves = 1, bool special = true);
 // Room to spare (two cells per lane, eight waves per workgroup): the Jacobian's three rows and the FD steps -- per-lane
 // arrays that are live from the first group evaluation of a Jacobian to the factorisation, across every RHS evaluation in
 // between -- move from registers to four more per-wave vectors behind the wave's scratch area.  At two waves per SIMD
@@ -152,15 +179,22 @@ __host__ __device__ constexpr int lds_listed(int cpl, int halves = 1, bool speci
     const int n = lds_vectors(cpl, halves, special) - 1;
     return n < NVEC - 1 ? n : NVEC - 1;
 }
+__host__ __device__ constexpr int lds_wave_doubles(int cpl, int halves, bool special)
+{
+    return two_of(cpl, halves, special) ? TWO_LDS_ROWS * 64 * cpl + two_f_lds(cpl, halves, special) * 64
+                                        : (lds_vectors(cpl, halves, special) + lds_extra(cpl, halves, special)) * 64 * cpl;
+}
+constexpr int TWO_GLOBAL_VECTORS = 14;   // TWO layout: JL JD JU HJ D3 Y FP D4 FAC D5 D6 D7 NZ Y0 (rank_two - TWO_LDS_ROWS)
 __host__ __device__ constexpr int spill_vectors(int cpl, int halves = 1, bool special = true)   // incl. V_Y0
 {
-    return two_of(cpl, halves, special) ? NVEC_TWO - lds_vectors(cpl, halves, special) : NVEC - lds_listed(cpl, halves, special);
+    return two_of(cpl, halves, special) ? TWO_GLOBAL_VECTORS : NVEC - lds_listed(cpl, halves, special);
 }
-// doubles of the global region one wave owns
+// doubles of the global region one wave owns (TWO: the vectors, the factorisation's lane-slots LDS has no room for, the
+// group evaluations of the Jacobian)
 __host__ __device__ constexpr int spill_doubles(int cpl, int halves = 1, bool special = true)
 {
     return spill_vectors(cpl, halves, special) * 64 * cpl +
-           (two_of(cpl, halves, special) ? TWO_LANE_SCALARS * 64 + TWO_GROUP_VECTORS * 64 * cpl : 0);
+           (two_of(cpl, halves, special) ? (two_f_slots(cpl, halves) - two_f_lds(cpl, halves, special)) * 64 + TWO_GROUP_VECTORS * 64 * cpl : 0);
 }
 // rank of a vector in the keep-in-LDS order D0..D5, Y, FP, D6, FAC, D7 (, Y0: never in LDS)
 __host__ __device__ constexpr int vec_rank(int v)
@@ -173,13 +207,17 @@ __host__ __device__ constexpr int vec_rank(int v)
 // Newton iteration reads -- the factorisation in the order the solve consumes it, so that the parts that fall to the
 // global region are the ones needed last -- then the Jacobian rows and the FD steps; the vectors the deep-column kernels
 // already keep in the global region come last.  (The predicted state / Jacobian base point has no vector: HC_YP_LOAD.)
+// Round 5: the noise vector no longer takes an LDS slot.  It is written when a row's noise is generated (or damped after a
+// failed attempt) and read ONCE per attempt -- across lanes, which a wave may do on its own global region after waiting for
+// its stores (one s_waitcnt per attempt; the CU's vector L1 is write-through and shared by the workgroup, so the wave's
+// own earlier stores are what its later loads see).  Its LDS goes to the factorisation, which every Newton iteration reads.
 __host__ __device__ constexpr int rank_two(int v)
 {
-    return v == V_NZ ? 0 : v == V_D0 ? 1 : v == V_D0 + 1 ? 2 : v == V_D0 + 2 ? 3 : v == V_FWF ? 4 : v == V_FWB ? 5 :
-           v == V_FL ? 6 : v == V_FU ? 7 : v == V_FIB ? 8 : v == V_JL ? 9 : v == V_JD ? 10 : v == V_JU ? 11 : v == V_HJ ? 12 :
-           v == V_D0 + 3 ? 13 : v == V_Y ? 14 : v == V_FP ? 15 : v == V_D0 + 4 ? 16 : v == V_FAC ? 17 :
-           v == V_D0 + 5 ? 18 : v == V_D0 + 6 ? 19 : v == V_D0 + 7 ? 20 : 21 /* V_Y0 */;
+    return v == V_D0 ? 0 : v == V_D0 + 1 ? 1 : v == V_D0 + 2 ? 2 : v == V_JL ? 3 : v == V_JD ? 4 : v == V_JU ? 5 : v == V_HJ ? 6 :
+           v == V_D0 + 3 ? 7 : v == V_Y ? 8 : v == V_FP ? 9 : v == V_D0 + 4 ? 10 : v == V_FAC ? 11 :
+           v == V_D0 + 5 ? 12 : v == V_D0 + 6 ? 13 : v == V_D0 + 7 ? 14 : v == V_NZ ? 15 : 16 /* V_Y0 */;
 }
+constexpr bool TWO_NZ_GLOBAL = true;
 
 // A wave's vectors: `lds` holds the first lds_listed(CPL) of the order above (then the noise vector, if it is in LDS),
 // `spill` the rest.  VEC is a compile-time id; the D-row accessors take the row as an unrolled loop index.
@@ -187,7 +225,8 @@ template <int CPL, int HALVES = 1, bool SP = true>
 struct WaveVecs {
     static constexpr int SLOTS = WAVE * CPL;
     static constexpr bool TWO = two_of(CPL, HALVES, SP);
-    static constexpr int N_LDS = TWO ? lds_vectors(CPL, HALVES, SP) : lds_listed(CPL, HALVES, SP);
+    static constexpr int N_LDS = TWO ? TWO_LDS_ROWS : lds_listed(CPL, HALVES, SP);
+    static constexpr int NF = two_f_slots(CPL, HALVES), F_LDS = TWO ? two_f_lds(CPL, HALVES, SP) : 0;
     // the global region through a buffer resource (see gld / gst): the TWO layout and, since round 4, the deep columns
 #ifndef HC_RSRC_MIN_CPL
 #define HC_RSRC_MIN_CPL 8      // (measured: 6 cells per lane -5 %, 7 -1.4 %, 8 +5 %, 9 +11 %, 10 +42 %; digests unchanged)
@@ -223,12 +262,25 @@ struct WaveVecs {
             else spill[(vec_rank(VEC) - N_LDS) * SLOTS + slot] = v;
         }
     }
-    // TWO layout: per-lane scalar k of the factorisation
-    __device__ __forceinline__ double ldS(int k, int lane) const { return gld((NVEC_TWO - N_LDS) * SLOTS * 8, (k * WAVE + lane) * 8); }
-    __device__ __forceinline__ void stS(int k, int lane, double v) const { gst((NVEC_TWO - N_LDS) * SLOTS * 8, (k * WAVE + lane) * 8, v); }
+    // TWO layout: lane-slot k of the factorisation (k is a constant after unrolling): the first F_LDS of them behind the
+    // difference rows in LDS, the rest behind the vectors of the global region
+    static constexpr int F_OFF = TWO_GLOBAL_VECTORS * SLOTS * 8;
+    __device__ __forceinline__ double ldF(int k, int lane) const
+    {
+        if (k < F_LDS) return lds[TWO_LDS_ROWS * SLOTS + k * WAVE + lane];
+        return gld(F_OFF, ((k - F_LDS) * WAVE + lane) * 8);
+    }
+    __device__ __forceinline__ void stF(int k, int lane, double v) const
+    {
+        if (k < F_LDS) lds[TWO_LDS_ROWS * SLOTS + k * WAVE + lane] = v;
+        else gst(F_OFF, ((k - F_LDS) * WAVE + lane) * 8, v);
+    }
+    // lane-slot of each entry: wf[1..], wb[..CPL-3], l / u / 1/b [..CPL-2], then the 14 scalars
+    static constexpr int K_WF = -1, K_WB = CPL - 1, K_L = 2 * CPL - 3, K_U = 3 * CPL - 4, K_IB = 4 * CPL - 5, K_S = 5 * CPL - 6;
+    static constexpr int K_SP = 5 * CPL + 8, K_UNI = 6 * CPL + 8;      // split column only
     // TWO layout: f of FD-Jacobian group evaluation g (stored whole, no read-modify-write of the Jacobian rows per group);
     // the finalising phase gathers row entries by each lane's own group ids
-    static constexpr int FG_OFF = ((NVEC_TWO - N_LDS) * SLOTS + TWO_LANE_SCALARS * WAVE) * 8;
+    static constexpr int FG_OFF = (TWO_GLOBAL_VECTORS * SLOTS + (NF - F_LDS) * WAVE) * 8;
     __device__ __forceinline__ void stG(int g_uniform, int slot, double v) const { gst(FG_OFF + g_uniform * (SLOTS * 8), slot * 8, v); }
     __device__ __forceinline__ double ldG(int g_lane, int slot) const { return gld(FG_OFF, g_lane * (SLOTS * 8) + slot * 8); }
     // TWO layout: the wave's global region through a buffer resource -- scalar base + scalar vector offset + per-lane
@@ -245,6 +297,24 @@ struct WaveVecs {
         const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, vec_bytes, 0);
         return __hiloint2double((int)r.y, (int)r.x);
     }
+    // Loads that must see what OTHER lanes (or, on the split column, the partner wave) stored to the region: the noise
+    // vector's cross-lane read.  sc0 | sc1: served from the L2, never from a line the vector L1 may still hold.
+    __device__ __forceinline__ double gld_fresh(int vec_bytes, int lane_bytes) const
+    {
+        const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, vec_bytes, 17);
+        return __hiloint2double((int)r.y, (int)r.x);
+    }
+    __amdgpu_buffer_rsrc_t rsrc_partner;       // split column: the other half's region
+    __device__ __forceinline__ void bind_partner(double *region_base)
+    {
+        rsrc_partner = __builtin_amdgcn_make_buffer_rsrc(region_base, 0, spill_doubles(CPL, HALVES, SP) * 8, 0x00020000);
+    }
+    __device__ __forceinline__ double gld_partner_fresh(int vec_bytes, int lane_bytes) const
+    {
+        const v2u_t r = __builtin_amdgcn_raw_buffer_load_b64(rsrc_partner, lane_bytes, vec_bytes, 17);
+        return __hiloint2double((int)r.y, (int)r.x);
+    }
+    static constexpr int NZ_OFF = TWO ? (rank_two(V_NZ) - TWO_LDS_ROWS) * SLOTS * 8 : 0;
     __device__ __forceinline__ void gst(int vec_bytes, int lane_bytes, double v) const
     {
         v2u_t r;
@@ -476,7 +546,10 @@ __device__ __forceinline__ void change_D(const WV &W, double *ru, int order, dou
 
 // bdf.py _step_impl after acceptance, for a compile-time order: D[order+2] = d - D[order+1]; D[order+1] = d;
 // D[k] += D[k+1] for k = order..0.  All rows are read before any is written (independent LDS reads).
-template <int CPL, int ORDER, class WV>
+// TOP2_LATER (TWO layout, round 5): D[order+2] is not stored here.  Nothing reads it unless the ORDER RISES at this very
+// step -- the next accepted step overwrites it, change_D and the predictor stop at row order(+1) -- and the caller, which
+// holds it in d_ord2, stores it in that case only (0.2 of 6.1 steps per column-step at D = 300).
+template <int CPL, int ORDER, bool TOP2_LATER, class WV>
 __device__ __forceinline__ void accept_update(const WV &W, const double (&dd)[CPL], int lane, double (&d_ord)[CPL],
                                               double (&d_ord2)[CPL])
 {
@@ -488,7 +561,7 @@ __device__ __forceinline__ void accept_update(const WV &W, const double (&dd)[CP
 #pragma unroll
         for (int k = 0; k <= ORDER + 1; k++) r[k] = W.ldD(k, slot);
         const double top2 = dd[c] - r[ORDER + 1];
-        W.stD(ORDER + 2, slot, top2);
+        if (!TOP2_LATER) W.stD(ORDER + 2, slot, top2);
         W.stD(ORDER + 1, slot, dd[c]);
         double acc = dd[c];
 #pragma unroll
@@ -752,9 +825,11 @@ __device__ __forceinline__ void col_stats(bool hasU, bool hasD, double fnU, doub
 }
 
 
+// PH_FBASE (TWO layout, round 5): f(y_predict) evaluated again when a Jacobian refresh needs it as its base value, instead
+// of stored at the first Newton iterate of every step (see HC_TWO_FP_LAZY)
 enum Phase {
     PH_F0 = 0, PH_F1, PH_JAC, PH_JAC_REDO, PH_NEWTON,
-    C_JAC_FIN, C_STEP_BEGIN, C_STEP_TRY, C_NEWTON_BEGIN, C_NEWTON_FAIL, C_ERR_TEST, C_ACCEPT,
+    C_JAC_FIN, C_STEP_BEGIN, C_STEP_TRY, C_NEWTON_BEGIN, C_NEWTON_FAIL, C_ERR_TEST, C_ACCEPT, PH_FBASE,
     C_SUCCESS, C_FAIL
 };
 
@@ -775,10 +850,37 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     constexpr int NEXTRA = lds_extra(CPL, HALVES, SPECIAL);
     constexpr bool J_LDS = NEXTRA == 4;
     constexpr bool TWO = two_of(CPL, HALVES, SPECIAL);       // hand-placed state, two waves per SIMD (see two_of)
+// Round 5, stores of the TWO layout's global region that bought nothing (each -D...=0 restores the round-4 form for A/B):
+//  * HC_TWO_FP_LAZY: the base value of a Jacobian REFRESH, f(y_predict), was stored at the first Newton iterate of every
+//    step (6.1 per column-step) and read by 0.004 refreshes per column-step.  It is now recomputed when a refresh happens:
+//    one more RHS evaluation at the predictor's state -- rebuilt from the difference rows by the same additions, so the
+//    same bits -- that the solver statistics do not count (scipy's fun(t_new, y_predict) of that iterate is the same call).
+//  * HC_TWO_J_ZERO_ONCE: the Jacobian rows were zeroed at the start of every attempt.  Every entry with a column is
+//    rewritten by the group scatter before anything reads it; entries without one (row 0's sub-diagonal, the last row's
+//    super-diagonal, the padding) are zero from the wave's first pass on (C_JAC_FIN stores 0.0 there) -- so they are
+//    zeroed once per launch.  With the rows gathered from the group evaluations (4 cells per lane) nothing is needed.
+//  * HC_TWO_Y_LAZY: the accepted-state vector is not rewritten with the row's start state at every attempt (it still holds
+//    it: the TWO layout only stores an accepted state when it can be the row's answer), and the separate copy of the
+//    row-start state is only kept where the spin-up stop rule reads it.
+#ifndef HC_TWO_FP_LAZY
+#define HC_TWO_FP_LAZY 1
+#endif
+#ifndef HC_TWO_J_ZERO_ONCE
+#define HC_TWO_J_ZERO_ONCE 1
+#endif
+#ifndef HC_TWO_Y_LAZY
+#define HC_TWO_Y_LAZY 1
+#endif
+#ifndef HC_TWO_TOP2_LATER      // see accept_update
+#define HC_TWO_TOP2_LATER 1
+#endif
 #ifndef HC_TWO_PARTS
 #define HC_TWO_PARTS 31       // development: bit 0 factorisation, 1 Jacobian rows, 2 predicted state, 3 group ids, 4 row-start state
 #endif
     constexpr bool TWO_F = TWO && (HC_TWO_PARTS & 1), TWO_J = TWO && (HC_TWO_PARTS & 2), TWO_YP = TWO && (HC_TWO_PARTS & 4);
+    constexpr bool FP_LAZY = TWO_YP && HC_TWO_FP_LAZY, J_ZERO_ONCE = TWO_J && HC_TWO_J_ZERO_ONCE;
+    constexpr bool Y_LAZY = TWO && (HC_TWO_PARTS & 16) && HC_TWO_Y_LAZY;
+    constexpr bool TOP2_LATER = TWO && HC_TWO_TOP2_LATER;
     // Group evaluations of the FD Jacobian stored whole and the rows gathered once (WaveVecs::stG / ldG) instead of a
     // read-modify-write of the three rows per group; the column parameters re-read from scalar memory at every RHS
     // evaluation instead of ~60 SGPRs held (and spilled) across the phases.  Measured at 65 536 members
@@ -798,7 +900,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #else
     constexpr bool P_RELOAD = TWO;
 #endif
-    constexpr int WSTRIDE = (NVEC_K + NEXTRA) * SLOTS + WAVE_SCRATCH;     // doubles per wave
+    constexpr int WAVE_LDS = lds_wave_doubles(CPL, HALVES, SPECIAL);      // the wave's vectors (TWO: + the factorisation's slots)
+    constexpr int WSTRIDE = WAVE_LDS + WAVE_SCRATCH;                      // doubles per wave
     static_assert(WPB == wpb_of(CPL, HALVES, SPECIAL), "the workgroup size the LDS layout was sized for");
     // chunk bookkeeping of the multi-point mode lives in the spare fourth row of the group-id table:
     // [0] next member of the chunk, [1] its end (-1: no chunk left), [2] point whose tables are in LDS, [3] the chunk's point
@@ -827,7 +930,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     const double *tabw = tab + hb;
     const signed char *gtabw = gtab + hb;
     double *V = wave_base + (size_t)wave * WSTRIDE;
-    double *ru = V + NVEC_K * SLOTS;
+    double *ru = V + (J_LDS ? NVEC_K * SLOTS : WAVE_LDS);
     double *jx = ru + WAVE_SCRATCH;       // [4][SLOTS] when J_LDS: Jacobian rows (sub, main, super) and FD steps
 #define HC_J_LOAD()                                                        \
     if constexpr (J_LDS) {                                                 \
@@ -895,38 +998,60 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     }
 // TWO layout: the factorisation is written once per lu_factor and read by every Newton iteration (no register of it is
 // live across an RHS evaluation); the predicted state / Jacobian base point likewise
+// (entries the solve never reads -- wf[0], wb of the last two cells, l / u / 1/b of the chunk's last row, which only feed
+//  the reduced system inside lu_factor -- have no lane-slot: 6 of 25 per lane were stored for nothing in round 4)
 #define HC_F_STORE()                                                       \
     if constexpr (TWO_F) {                                                   \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
-            const int s_ = c * WAVE + lane;                                \
-            W.template st<V_FWF>(s_, F.wf[c]);                             \
-            W.template st<V_FWB>(s_, F.wb[c]);                             \
-            W.template st<V_FL>(s_, F.l[c]);                               \
-            W.template st<V_FU>(s_, F.u[c]);                               \
-            W.template st<V_FIB>(s_, F.ib[c]);                             \
+            if (c >= 1) W.stF(W.K_WF + c, lane, F.wf[c]);                  \
+            if (c <= CPL - 3) W.stF(W.K_WB + c, lane, F.wb[c]);            \
+            if (c <= CPL - 2) {                                            \
+                W.stF(W.K_L + c, lane, F.l[c]);                            \
+                W.stF(W.K_U + c, lane, F.u[c]);                            \
+                W.stF(W.K_IB + c, lane, F.ib[c]);                          \
+            }                                                              \
         }                                                                  \
-        W.stS(0, lane, F.wx);                                              \
-        W.stS(1, lane, F.invB);                                            \
+        W.stF(W.K_S + 0, lane, F.wx);                                      \
+        W.stF(W.K_S + 1, lane, F.invB);                                    \
         _Pragma("unroll") for (int q = 0; q < 6; q++) {                    \
-            W.stS(2 + q, lane, F.al[q]);                                   \
-            W.stS(8 + q, lane, F.ga[q]);                                   \
+            W.stF(W.K_S + 2 + q, lane, F.al[q]);                           \
+            W.stF(W.K_S + 8 + q, lane, F.ga[q]);                           \
+        }                                                                  \
+        if constexpr (HALVES == 2) {                                       \
+            _Pragma("unroll") for (int c = 0; c < CPL; c++) W.stF(W.K_SP + c, lane, F.sp[c]); \
+            const double uni_ = lane == 0 ? F.couple : lane == 1 ? F.couple_other : lane == 2 ? F.g_up : \
+                                lane == 3 ? F.g_lo : F.inv_den;            \
+            W.stF(W.K_UNI, lane, uni_);                                    \
         }                                                                  \
     }
 #define HC_F_LOAD()                                                        \
     if constexpr (TWO_F) {                                                   \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
-            const int s_ = c * WAVE + lane;                                \
-            F.wf[c] = W.template ld<V_FWF>(s_);                            \
-            F.wb[c] = W.template ld<V_FWB>(s_);                            \
-            F.l[c] = W.template ld<V_FL>(s_);                              \
-            F.u[c] = W.template ld<V_FU>(s_);                              \
-            F.ib[c] = W.template ld<V_FIB>(s_);                            \
+            F.wf[c] = c >= 1 ? W.ldF(W.K_WF + c, lane) : 0.0;              \
+            F.wb[c] = c <= CPL - 3 ? W.ldF(W.K_WB + c, lane) : 0.0;        \
+            if (c <= CPL - 2) {                                            \
+                F.l[c] = W.ldF(W.K_L + c, lane);                           \
+                F.u[c] = W.ldF(W.K_U + c, lane);                           \
+                F.ib[c] = W.ldF(W.K_IB + c, lane);                         \
+            } else {                                                       \
+                F.l[c] = F.u[c] = 0.0;                                     \
+                F.ib[c] = 1.0;                                             \
+            }                                                              \
         }                                                                  \
-        F.wx = W.ldS(0, lane);                                             \
-        F.invB = W.ldS(1, lane);                                           \
+        F.wx = W.ldF(W.K_S + 0, lane);                                     \
+        F.invB = W.ldF(W.K_S + 1, lane);                                   \
         _Pragma("unroll") for (int q = 0; q < 6; q++) {                    \
-            F.al[q] = W.ldS(2 + q, lane);                                  \
-            F.ga[q] = W.ldS(8 + q, lane);                                  \
+            F.al[q] = W.ldF(W.K_S + 2 + q, lane);                          \
+            F.ga[q] = W.ldF(W.K_S + 8 + q, lane);                          \
+        }                                                                  \
+        if constexpr (HALVES == 2) {                                       \
+            _Pragma("unroll") for (int c = 0; c < CPL; c++) F.sp[c] = W.ldF(W.K_SP + c, lane); \
+            const double uni_ = W.ldF(W.K_UNI, lane);                      \
+            F.couple = readlane_d(uni_, 0);                                \
+            F.couple_other = readlane_d(uni_, 1);                          \
+            F.g_up = readlane_d(uni_, 2);                                  \
+            F.g_lo = readlane_d(uni_, 3);                                  \
+            F.inv_den = readlane_d(uni_, 4);                               \
         }                                                                  \
     }
 // TWO layout: the Jacobian's base point is not kept anywhere: it is D[0] for the first Jacobian of an attempt (y0) and the
@@ -980,7 +1105,17 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     W.spill = (__attribute__((address_space(1))) double *)A.wave_spill +
               ((size_t)blockIdx.x * WPB + (W.RSRC ? uniform_i(wave) : wave)) * (size_t)spill_doubles(CPL, HALVES, SPECIAL);
     if constexpr (W.RSRC) W.bind(A.wave_spill + ((size_t)blockIdx.x * WPB + uniform_i(wave)) * (size_t)spill_doubles(CPL, HALVES, SPECIAL));
+    if constexpr (TWO && HALVES == 2)
+        W.bind_partner(A.wave_spill + ((size_t)blockIdx.x * WPB + (uniform_i(wave) ^ 1)) * (size_t)spill_doubles(CPL, HALVES, SPECIAL));
     change_D_init(ru, lane);
+    if constexpr (J_ZERO_ONCE && !JG) {
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            W.template st<V_JL>(c * WAVE + lane, 0.0);
+            W.template st<V_JD>(c * WAVE + lane, 0.0);
+            W.template st<V_JU>(c * WAVE + lane, 0.0);
+        }
+    }
     const int D = A.D;
     const double inv_sqrt_d = 1.0 / sqrt((double)D);
 
@@ -1180,11 +1315,13 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             // the integrator
             // (measured at CPL = 5: the register copy is 0.5 % faster, so it stays there)
             double yrow0[DEEPY ? 1 : CPL];
+            if (!Y_LAZY || A.spin_stop) {
 #pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                const double y0c = W.template ld<V_Y>(c * WAVE + lane);
-                if (DEEPY) W.template st<V_Y0>(c * WAVE + lane, y0c);
-                else yrow0[DEEPY ? 0 : c] = y0c;
+                for (int c = 0; c < CPL; c++) {
+                    const double y0c = W.template ld<V_Y>(c * WAVE + lane);
+                    if (DEEPY) W.template st<V_Y0>(c * WAVE + lane, y0c);
+                    else yrow0[DEEPY ? 0 : c] = y0c;
+                }
             }
             // ---- up to 5 attempts (richards_pde.py:509-533)
             for (;;) {
@@ -1193,10 +1330,15 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                 // top-node cell (lane 63, last slot) uses n_rnd[0]   
                 double rnd[CPL];
                 if constexpr (HALVES == 2) {       // both halves' noise vectors are in place before either reads across the cut
+                    // (TWO layout: "in place" = this wave's stores to its global region have completed)
+                    if constexpr (TWO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const double mine[1] = {0.0};
                     double theirs[1];
                     comm.xchg(mine, theirs);
                 }
+                // (noise vector in the wave's global region: its stores -- generation, or the x0.8 of a failed attempt -- have
+                //  landed before other lanes' slots are read; at workgroup scope this is an s_waitcnt, no cache operation)
+                if constexpr (TWO && TWO_NZ_GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
                     const int i = hb + lane * CPL + c;
@@ -1205,8 +1347,17 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     double z;
                     if constexpr (HALVES == 2) {
                         const int wl = idx / CPL, sl = (idx % CPL) * WAVE + (wl & (WAVE - 1));
-                        const double own = W.template ld<V_NZ>(sl), other = nz_partner[sl];
+                        double own, other;
+                        if constexpr (TWO) {
+                            own = W.gld_fresh(W.NZ_OFF, sl * 8);
+                            other = W.gld_partner_fresh(W.NZ_OFF, sl * 8);
+                        } else {
+                            own = W.template ld<V_NZ>(sl);
+                            other = nz_partner[sl];
+                        }
                         z = (wl >> 6) == comm.half ? own : other;
+                    } else if constexpr (TWO) {
+                        z = W.gld_fresh(W.NZ_OFF, ((idx % CPL) * WAVE + idx / CPL) * 8);
                     } else {
                         z = W.template ld<V_NZ>((idx % CPL) * WAVE + idx / CPL);
                     }
@@ -1225,16 +1376,17 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                 for (int c = 0; c < CPL; c++) {
                     // sol.y[:, -1] before any accepted step is y0 itself
                     double y0c;
-                    if (DEEPY) y0c = attempts == 1 ? W.template ld<V_Y>(c * WAVE + lane) : W.template ld<V_Y0>(c * WAVE + lane);
+                    if (Y_LAZY) y0c = W.template ld<V_Y>(c * WAVE + lane);   // (still the row's start state: see HC_TWO_Y_LAZY)
+                    else if (DEEPY) y0c = attempts == 1 ? W.template ld<V_Y>(c * WAVE + lane) : W.template ld<V_Y0>(c * WAVE + lane);
                     else y0c = yrow0[DEEPY ? 0 : c];
                     ycur[c] = y0c;
-                    W.template st<V_Y>(c * WAVE + lane, y0c);
+                    if (!Y_LAZY) W.template st<V_Y>(c * WAVE + lane, y0c);
                     W.stD(0, c * WAVE + lane, ycur[c]);
                     W.template st<V_FAC>(c * WAVE + lane, SQRT_EPS);
                     yp[c] = psiv[c] = dd[c] = jl[c] = jd[c] = ju[c] = hj[c] = 0.0;
                     scl[c] = 1.0;
                 }
-                HC_J_STORE();
+                if constexpr (!J_ZERO_ONCE) { HC_J_STORE(); }
                 int phase = PH_F0;
                 // column parameters: one scalar-memory read per attempt.  (Per RHS evaluation the lone wave sat out
                 // the load latency 24 times per row; for the kernel's lifetime they cost ~60 SGPRs, see DESIGN.md.)
@@ -1277,9 +1429,9 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             // two waves per SIMD: the column parameters come from scalar memory at every evaluation (the
                             // other wave covers the load) instead of ~60 SGPRs held -- and spilled -- across the phases
                             const ColumnDev Pe = load_const(A.P + point);
-                            rhs_eval<CPL, SPECIAL, PREDICT>(Pe, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
+                            rhs_eval<CPL, SPECIAL, PREDICT, TWO>(Pe, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
                         } else {
-                            rhs_eval<CPL, SPECIAL, PREDICT>(P, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
+                            rhs_eval<CPL, SPECIAL, PREDICT, TWO>(P, R, tabw, lane, ycur, rnd, f, nullptr, diag_tr, diag_lf, comm HC_RHS_PROF_ARG);
                         }
                         HC_STAMP(17);   // after the RHS: dispatch to the phase block
                     }
@@ -1340,7 +1492,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         HC_STAMP(PH_NEWTON);
                         // solve_bdf_system, iteration newton_k
                         nfev++;
-                        if (newton_k == 0 && !current_jac) {   // f(y_predict): base value of a Jacobian refresh
+                        if (!FP_LAZY && newton_k == 0 && !current_jac) {   // f(y_predict): base value of a Jacobian refresh
 #pragma unroll
                             for (int c = 0; c < CPL; c++) W.template st<V_FP>(c * WAVE + lane, f[c]);
                         }
@@ -1405,6 +1557,14 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             n_equal = 0;
                             have_lu = 0;
                             phase = C_STEP_TRY;
+                        } else if constexpr (FP_LAZY) {
+                            // J = jac(t_new, y_predict): its base value f(y_predict) is evaluated again (PH_FBASE below)
+                            jac_init = 0;
+                            HC_YP_LOAD();
+#pragma unroll
+                            for (int c = 0; c < CPL; c++) ycur[c] = yp[c];
+                            guard--;       // (the extra trip is not the integrator's: the budget counts what round 4 counted)
+                            phase = PH_FBASE;
                         } else {
                             // J = jac(t_new, y_predict): base point yp, base f = fun(y_predict) kept in V_FP
                             njev++;
@@ -1412,6 +1572,15 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             g = -1;
                             phase = PH_JAC;
                         }
+                    }
+                    if (phase == PH_FBASE && have_f) {
+                        have_f = false;
+                        HC_STAMP(PH_FBASE);
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) W.template st<V_FP>(c * WAVE + lane, f[c]);
+                        njev++;
+                        g = -1;
+                        phase = PH_JAC;
                     }
                     if (phase == PH_JAC_REDO && have_f) {
                         have_f = false;
@@ -1712,11 +1881,11 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             for (int c = 0; c < CPL; c++) W.template st<V_Y>(c * WAVE + lane, ycur[c]);
                         }
                         switch (order) {
-                            case 1: HC_SUB(41); accept_update<CPL, 1>(W, dd, lane, d_ord, d_ord2); break;
-                            case 2: HC_SUB(42); accept_update<CPL, 2>(W, dd, lane, d_ord, d_ord2); break;
-                            case 3: HC_SUB(43); accept_update<CPL, 3>(W, dd, lane, d_ord, d_ord2); break;
-                            case 4: HC_SUB(44); accept_update<CPL, 4>(W, dd, lane, d_ord, d_ord2); break;
-                            default: HC_SUB(45); accept_update<CPL, 5>(W, dd, lane, d_ord, d_ord2); break;
+                            case 1: HC_SUB(41); accept_update<CPL, 1, TOP2_LATER>(W, dd, lane, d_ord, d_ord2); break;
+                            case 2: HC_SUB(42); accept_update<CPL, 2, TOP2_LATER>(W, dd, lane, d_ord, d_ord2); break;
+                            case 3: HC_SUB(43); accept_update<CPL, 3, TOP2_LATER>(W, dd, lane, d_ord, d_ord2); break;
+                            case 4: HC_SUB(44); accept_update<CPL, 4, TOP2_LATER>(W, dd, lane, d_ord, d_ord2); break;
+                            default: HC_SUB(45); accept_update<CPL, 5, TOP2_LATER>(W, dd, lane, d_ord, d_ord2); break;
                         }
                         HC_SUB_END();
                         if (t == tf) {
@@ -1746,6 +1915,14 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             double fbest = f0;
                             if (f1 > fbest) { best = 1; fbest = f1; }
                             if (f2 > fbest) { best = 2; fbest = f2; }
+                            if (TOP2_LATER && best == 2) {      // the order rises: D[order + 2] of this step is read from now on
+                                switch (order) {
+                                    case 1: _Pragma("unroll") for (int c = 0; c < CPL; c++) W.stD(3, c * WAVE + lane, d_ord2[c]); break;
+                                    case 2: _Pragma("unroll") for (int c = 0; c < CPL; c++) W.stD(4, c * WAVE + lane, d_ord2[c]); break;
+                                    case 3: _Pragma("unroll") for (int c = 0; c < CPL; c++) W.stD(5, c * WAVE + lane, d_ord2[c]); break;
+                                    default: _Pragma("unroll") for (int c = 0; c < CPL; c++) W.stD(6, c * WAVE + lane, d_ord2[c]); break;
+                                }
+                            }
                             order += best - 1;
                             const double factor = fmin(10.0, safety * fbest);
                             h_abs *= factor;
@@ -1879,7 +2056,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             yv[c] = W.template ld<V_Y>(c * WAVE + lane);
             unsat[c] = vnode[c] && !(yv[c] >= psi_sat_m);
         }
-        int istar = deepest_true<CPL>(unsat);
+        int istar = deepest_true<CPL, TWO>(unsat);
         if constexpr (HALVES == 2) istar = comm.max_int(istar < 0 ? -1 : hb + istar);
         int w = istar < 0 ? 0 : istar + 1;
         w = w < D - 1 ? w : D - 1;

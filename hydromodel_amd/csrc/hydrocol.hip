@@ -92,15 +92,17 @@ struct hc_handle {
     // split column (two waves per member, hc_device.h Comm<2>): columns of 513..640 nodes with one parameter point and
     // the root zone inside the upper half; its own slot layout of the tables (point 0 only)
     // HYDROCOL_SPLIT_COLUMN=0 keeps the one-wave kernels, =1 takes the split column wherever it applies (A/B, cross-checks).
-    // Default since round 4: the split column from 10 cells per lane on (D = 577..640).  With the deep kernels' global
-    // region behind a buffer resource the one-wave kernel at 9 cells per lane (D = 513..576) overtook it: 97.0 k against
-    // 95.7 k column-days/s, generic exponents 76.2 k against 68.6 k; at 10 cells per lane the split column still wins
-    // (95.8 k against 80.0 k, generic 68.7 k against 51.7 k) -- profiles/r04_depths.txt
+    // Round 4 default: the split column from 10 cells per lane on (D = 577..640); the one-wave kernel of 9 cells per lane
+    // (global region behind a buffer resource) had overtaken it at D = 513..576 (97.0 k against 95.7 k column-days/s).
+    // Round 5: the split column on the TWO layout -- four pairs per CU -- runs 125 k at every depth it serves (generic
+    // exponents 73 k) and is the default from 513 nodes on (use_pair below; profiles/r05_split_column_two.txt)
     bool pair_ok = false, no_split = false, force_split = false;
     std::vector<double> tab_pair_host;
     DevBuf<double> tab_pair;
     DevBuf<int> gtab_pair;
-    bool use_pair() const { return pair_ok && !no_split && (force_split || cpl >= 10); }
+    // (round 5: the split column runs on the TWO layout, four pairs per CU -- 125 k column-days/s at D = 513 ... 640 against
+    //  96 k of the one-wave kernel of 9 cells per lane at D = 541 -- so it is the default from 513 nodes on)
+    bool use_pair() const { return pair_ok && !no_split && (force_split || cpl >= 9); }
     int chunk_members = 0;       // HYDROCOL_CHUNK_MEMBERS (0: derived from the member count)
     DevBuf<double> tab, node_tabs, precip, atm, psi, base, nscale, fresh, psi_rows, scratch_d, diag;
     DevBuf<double> wave_spill;   // per-wave vectors of deep columns that do not fit in LDS (hc_step.h WaveVecs)
@@ -787,6 +789,23 @@ int hc_set_forcing(hc_handle *h, int64_t n_rows, const double *precip, const dou
     h->n_rows = n_rows;
     h->moments_points = 0;       // (re)allocated and zeroed by the next call that needs the moment tables
     h->have_forcing = true;
+    return HC_OK;
+}
+
+int hc_set_forcing_row(hc_handle *h, int64_t row, double precip, double atm, uint8_t daylight, int32_t wtd_obs)
+{
+    if (!h || !h->have_forcing) return fail(HC_ERR_ARG, "hc_set_forcing_row: hc_set_forcing has not been called");
+    if (row < 0 || row >= h->n_rows) return fail(HC_ERR_ARG, "hc_set_forcing_row: row %lld outside [0, %lld)", (long long)row,
+                                                 (long long)h->n_rows);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const unsigned char zero = 0;
+    HIP_TRY(hipMemcpy(h->precip.p + row, &precip, 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->atm.p + row, &atm, 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->daylight.p + row, &daylight, 1, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->wtd_obs.p + row, &wtd_obs, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->refresh.p + row, &zero, 1, hipMemcpyHostToDevice));
+    h->h_refresh[(size_t)row] = 0;
     return HC_OK;
 }
 

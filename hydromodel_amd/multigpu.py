@@ -15,7 +15,6 @@ a GPU, never a re-exec -- and every rank runs its share with no communication wh
 Rank 0 owns the output file.  Integer moment sums are order-independent: the file is bit-identical at any rank count.
 """
 import os
-import socket
 import subprocess
 import sys
 
@@ -38,13 +37,14 @@ def in_rank():
 def launch_ranks(n_ranks, script, argv):
     """Start ``n_ranks`` ranks of ``python script argv...`` as children of torch.distributed.run and return the launcher's
     exit code.  Must run before anything in this process has initialised a GPU."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # --standalone: the launcher's own c10d store picks a free port on 127.0.0.1 and hands it to the ranks (no
+    # bind-close-reuse of a port another process can take in between)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HYDROCOL_EXPECT_WORLD=str(n_ranks))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)] + list(argv)
+               HYDROCOL_EXPECT_WORLD=str(n_ranks))
+    for k in ("MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n_ranks), str(script)] + list(argv)
     return subprocess.run(cmd, env=env).returncode
 
 

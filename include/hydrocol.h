@@ -122,6 +122,11 @@ int hc_set_generic_exponents(hc_handle *h, int32_t on);
 int hc_set_forcing(hc_handle *h, int64_t n_rows, const double *precip, const double *atm,
                    const uint8_t *daylight, const int32_t *wtd_obs, const uint8_t *refresh);
 
+/* One row of the forcing replaced in place (row < n_rows of hc_set_forcing; its refresh flag is cleared): what the
+ * row-by-row caller of src/simulation.py:590-609 knows only when it reaches the row -- args_i["wtd"], ["atm"],
+ * ["time"], ["precipitation"] -- handed over just before `pde_model.solve(t_span, y0, args_i)` (hydromodel_amd/pde.py). */
+int hc_set_forcing_row(hc_handle *h, int64_t row, double precip, double atm, uint8_t daylight, int32_t wtd_obs);
+
 int hc_set_members(hc_handle *h, int64_t n_members);
 /* psi: [n_members][D] (broadcast 0), [D] copied to every member (1), or [n_points][D] copied to the members of
  * each parameter point (2) */

@@ -7,6 +7,9 @@
  */
 #include "hydro_oracle.h"
 
+static int g_scipy_152 = 0;              /* 1: select_initial_step as scipy 1.5.2 has it (no clamp to the interval) */
+static __thread long g_clamp_counts[3] = {0, 0, 0};   /* per calling thread */
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -408,6 +411,15 @@ typedef struct {
 /* test hooks: override EPS**0.875 to exercise num_jac's retry branch; count how often it is taken */
 static double g_jac_reject = NUM_JAC_DIFF_REJECT;
 static long g_jac_retry_count = 0;
+/* scipy 1.5.2 (the reference's pin) against >= 1.9 (installed): see select_initial_step in bdf_integrate */
+void ho_set_scipy_152(int on) { g_scipy_152 = on != 0; }
+/* [0] solves whose h0 exceeded the interval, [1] solves whose min(100 h0, h1) did, [2] solves counted; reset by a call with reset != 0 */
+void ho_clamp_counts(long *out3, int reset)
+{
+    for (int k = 0; k < 3; k++) out3[k] = g_clamp_counts[k];
+    if (reset) g_clamp_counts[0] = g_clamp_counts[1] = g_clamp_counts[2] = 0;
+}
+
 void ho_debug_set_jac_reject(double v) { g_jac_reject = v > 0.0 ? v : NUM_JAC_DIFF_REJECT; }
 long ho_debug_jac_retry_count(void) { return g_jac_retry_count; }
 
@@ -659,7 +671,12 @@ static int bdf_integrate(bdf_t *b, double t0, double tf, const double *y0, doubl
         for (int i = 0; i < n; i++) tmp[i] = f[i] / scale[i];
         double d1 = rms_norm(tmp, n);
         double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-        h0 = h0 < interval ? h0 : interval;
+        /* scipy >= 1.9 clamps h0 and the returned step to the interval (common.py select_initial_step(..., t_bound, ...));
+         * the reference's pinned scipy==1.5.2 has neither clamp and leaves an over-long first step to _step_impl's
+         * `t_new - t_bound > 0` rule (change_D by the ratio).  The golden vectors were made with 1.15.3; the switch
+         * below runs the 1.5.2 form and the counters say how often the two differ on this path. */
+        if (h0 > interval) g_clamp_counts[0]++;
+        if (!g_scipy_152) h0 = h0 < interval ? h0 : interval;
         double y1[HO_MAXD], f1[HO_MAXD];
         for (int i = 0; i < n; i++) y1[i] = y[i] + h0 * 1.0 * f[i];
         fun(b, y1, f1);
@@ -673,7 +690,11 @@ static int bdf_integrate(bdf_t *b, double t0, double tf, const double *y0, doubl
             h1 = pow(0.01 / np_maximum(d1, d2), 1.0 / 2.0);
         h_abs = 100 * h0;
         if (h1 < h_abs) h_abs = h1;
-        if (interval < h_abs) h_abs = interval;
+        g_clamp_counts[2]++;
+        if (interval < h_abs) {
+            g_clamp_counts[1]++;
+            if (!g_scipy_152) h_abs = interval;
+        }
     }
     double newton_tol = np_maximum(10 * EPS / rtol, np_minimum(0.03, sqrt(rtol)));
     b->have_factor = 0;

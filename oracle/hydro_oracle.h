@@ -97,6 +97,11 @@ void ho_run_diag(const ho_column *c, int64_t T, const double *precip, const doub
                  int64_t row_begin, int64_t row_end, double *psi, double *base_noise, double *fresh,
                  int32_t *wtd_est, double *diag);
 
+/* scipy==1.5.2 (the reference's pin, requirements.txt:4) has no clamp of the initial step to the interval; on != 0 runs that
+ * form.  ho_clamp_counts: [0] solves whose h0 exceeded the interval, [1] solves whose min(100 h0, h1) did, [2] all solves. */
+void ho_set_scipy_152(int on);
+void ho_clamp_counts(long *out3, int reset);
+
 /* test hooks (num_jac retry branch) */
 void ho_debug_set_jac_reject(double v);
 long ho_debug_jac_retry_count(void);

@@ -83,6 +83,10 @@ def lib():
         L.ho_run_diag.argtypes = [C.POINTER(HoColumn), C.c_int64, _dp, _dp, _bp, _ip, _bp, C.c_int64,
                                   C.c_int64, _dp, _dp, _dp, _ip, _dp]
         L.ho_run_diag.restype = None
+        L.ho_set_scipy_152.argtypes = [C.c_int]
+        L.ho_set_scipy_152.restype = None
+        L.ho_clamp_counts.argtypes = [C.POINTER(C.c_long), C.c_int]
+        L.ho_clamp_counts.restype = None
         L.ho_debug_set_jac_reject.argtypes = [C.c_double]
         L.ho_debug_set_jac_reject.restype = None
         L.ho_debug_jac_retry_count.argtypes = []
@@ -170,6 +174,18 @@ class Oracle:
         M = self.D - 1
         return out, {"c": aux[:M], "s": aux[M:2 * M], "f": aux[2 * M:3 * M], "pL": aux[3 * M],
                      "tr_lf_first": aux[3 * M + 1:3 * M + 3], "tr_lf_int": aux[3 * M + 3:3 * M + 5]}
+
+    @staticmethod
+    def set_scipy_152(on):
+        """select_initial_step as the reference's pinned scipy==1.5.2 has it (no clamp to the interval); off = scipy >= 1.9."""
+        lib().ho_set_scipy_152(int(bool(on)))
+
+    @staticmethod
+    def clamp_counts(reset=False):
+        """(solves whose h0 exceeded the interval, solves whose min(100 h0, h1) did, all solves) on this thread."""
+        out = (C.c_long * 3)()
+        lib().ho_clamp_counts(out, int(bool(reset)))
+        return int(out[0]), int(out[1]), int(out[2])
 
     @staticmethod
     def last_arg_out():

@@ -16,6 +16,7 @@ Usage:
     python tests/golden/make_golden.py profiles   # G1 tables for the Constant / Linear / Exponential porosity and the other root pdfs
     python tests/golden/make_golden.py points_short  # first 240 rows of year-long runs at two of those points, ~1 min
     python tests/golden/make_golden.py short      # first days of vanGenuchten / HLIFT / ET+LF-off runs, ~1 min
+    python tests/golden/make_golden.py spinup     # the reference's spin-up: solves used, first 12 states (wells 1 and 200), ~3 min
     python tests/golden/make_golden.py deep       # G1, G3/G4 and the first 96 rows at the reference's deepest well (no. 14, D = 581)
 
 Vector families:
@@ -467,6 +468,30 @@ def g5_short(well_no, tmp, n_rows, model="vrettas_fung", flags=None, overrides=N
             "flags": np.array([int(bool(m["sim_flags"][k])) for k in ("SPINUP", "ET", "LF", "HLIFT", "PREDICT")])}
 
 
+def g1_spinup(well_no, tmp, keep=12):
+    """Simulation.initial_conditions (simulation.py:389-493) as the reference runs it inside setupModel: how many solves
+    it took, the start state, the state after each of the first `keep` solves and the solver statistics of those."""
+    states, starts = [], []
+    orig = ref_pde.RichardsPDE.solve
+
+    def recording_solve(self, t_span, y0, *args):
+        starts.append(np.array(y0, dtype=float))
+        y = orig(self, t_span, y0, *args)
+        states.append(np.array(y, dtype=float))
+        return y
+
+    ref_pde.RichardsPDE.solve = recording_solve
+    try:
+        with _SolveRecorder() as rec:
+            sim, _, _ = _setup(well_no, tmp)
+    finally:
+        ref_pde.RichardsPDE.solve = orig
+    assert np.array_equal(states[-1], sim.mData["initial_cond"])
+    stats = np.array([c[:4] for c in rec.calls[:keep]], dtype=np.int64)
+    return {"iterations": np.array(len(states)), "attempts_total": np.array(len(rec.calls)), "y_start": starts[0],
+            "y_first": np.array(states[:keep]), "stats_first": stats, "initial_cond": sim.mData["initial_cond"]}
+
+
 def _save(name, arrays):
     meta = json.dumps(VERSIONS)
     np.savez_compressed(HERE / name, _meta=np.array(meta), **arrays)
@@ -519,6 +544,9 @@ def main(argv):
             _save("g1_tables_401.npz", g1_tables(sim))
             _save("g34_states_401.npz", g34_states(sim))
             _save("g5s_default_well_401.npz", g5_short(401, tmp, 96))
+        elif mode == "spinup":
+            for well in (1, 200):
+                _save(f"g1s_spinup_{well}.npz", g1_spinup(well, tmp))
         elif mode == "short":
             _save("g5s_vangenuchten_200.npz", g5_short(200, tmp, 480, model="vanGenuchten"))
             _save("g5s_hlift_200.npz", g5_short(200, tmp, 240, flags={"HLIFT": True}))

@@ -90,7 +90,7 @@ def test_every_kernel_unit_is_built_and_the_scheduler_table_names_real_units():
                 (len(group) == 2 and group[0] == "-mllvm" and group[1].startswith("-amdgpu-"))
     # the units compiled as TWO-layout kernels are exactly the ones with source-determined contraction
     two = {k for k, groups in ge.UNIT_FLAGS.items() if ("-ffp-contract=on",) in groups}
-    assert two == {(4, 1), (5, 1), (6, 1), (4, 0), (5, 0)}
+    assert two == {(4, 1), (5, 1), (6, 1), (4, 0), (5, 0), (6, 0), "pair"}       # (round 5: + generic 6 cells, + the split column)
     src = (ge.CSRC / "hc_inst.hip").read_text()
     assert "HC_INST_SPECIAL" in src and "HC_INST_PAIR" in src
 
@@ -110,3 +110,9 @@ def test_a_hipcc_without_a_tuning_option_still_builds_the_unit(tmp_path, monkeyp
     monkeypatch.setattr(ge, "flag_supported", lambda group: True)
     lib = ge.build_library(tmp_path / "lib_fallback.so", cpls=(2,), defines=("-DHC_CPL_MASK=4",), obj_dir=tmp_path / "obj", force=True)
     assert lib.exists() and lib.stat().st_size > 100_000
+    # the library's device-code identity says how its units were REALLY built: the unit that fell back is hashed
+    # without its tuning words, the stamp next to the host object holds that identity, and hc_version() carries it
+    assert (tmp_path / "obj" / "hc_inst_cpl2s.fellback").exists()
+    stamp = (tmp_path / "obj" / "hydrocol.kernel_hash").read_text().strip()
+    assert stamp == ge.kernel_hash(("-DHC_CPL_MASK=4",), fell_back=((2, 1),)) != ge.kernel_hash(("-DHC_CPL_MASK=4",))
+    assert stamp.encode() in lib.read_bytes()

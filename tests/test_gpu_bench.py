@@ -23,7 +23,8 @@ def _run(cmd, timeout=600):
 
 def test_bench_contract_one_rank():
     out = _run([sys.executable, "bench.py", "--members", "4096", "--steps", "2", "--warmup", "1", "--cpu-seconds", "4",
-                "--sustained-members", "2048", "--sustained-days", "3", "--heavy-members", "1024", "--heavy-days", "2"])
+                "--sustained-members", "2048", "--sustained-days", "3", "--heavy-members", "1024", "--heavy-days", "2",
+                "--n1e6-members", "8192", "--n1e6-days", "2"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sustained", "sustained_heavy",
                 "ranks", "backend"):
@@ -44,10 +45,20 @@ def test_bench_contract_one_rank():
     consts = json.loads((REPO / "profiles" / "pmc_constants.json").read_text())
     from hydromodel_amd import _lib
     if consts["kernel_hash"] == _lib.kernel_hash():
-        assert r["traffic"] == consts["kernels"]["300/special"]["hbm_bytes_per_member_launch"] * 4096
-        assert "profiles/r04_pmc_fetch_cpl5.csv" in r["traffic_source"] and out["valu_f64"]["frac"] > 0.05
+        assert r["traffic"] == consts["kernels"]["300/special"]["fabric_bytes_per_member_launch"] * 4096
+        assert "profiles/r05_pmc_300_special_fetch.csv" in r["traffic_source"] and out["valu_f64"]["frac"] > 0.05
+        # the fabric leg prices that traffic (Infinity-Cache + HBM requests) against the guide's measured rates
+        f = r["fabric"]
+        assert f["unit"] == "GB/s" and f["peak"] == 8600.0 and f["hbm_achievable"] == 6290.0
+        assert abs(f["achieved"] - r["traffic"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-6 * f["achieved"]
+        assert abs(f["traffic_over_algorithmic"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 1e-9
     else:
-        assert r["traffic"] is None and "re-run tools/gpu_r4_pmc.sh" in r["traffic_source"]
+        assert r["traffic"] is None and r["fabric"] is None and "re-run tools/gpu_r5_pmc.sh" in r["traffic_source"]
+    # per-launch spread of the timed steps (one launch per step at this size)
+    assert r["launches"] == 2 and r["launch_ms_min"] <= r["launch_ms"] <= r["launch_ms_max"]
+    n6 = out["n1e6"]
+    assert n6["members"] == 8192 and n6["days"] == 2 and n6["members_counted_last_row"] == 8192 and n6["value"] > 1e4
+    assert len(out["moments_sha1"]) == 40
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "members" in c["sample"]
     assert c["cores"] == c["host_cores_usable"] and abs(c["per_core"] * c["cores"] - c["value"]) < 1e-9 * c["value"]
@@ -68,10 +79,32 @@ def test_bench_two_ranks_share_the_moments():
     # whole-job aggregate: both ranks' members over the max-over-ranks time
     assert abs(two["value"] - 2 * 2048 * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-6 * two["value"]
     one = _run([sys.executable, "bench.py", "--members", "4096", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
-                "--no-sustained"])
+                "--no-sustained", "--no-heavy", "--no-n1e6"])
     # members are keyed by their global id: 2 x 2048 sharded == 4096 on one rank, to the last bit of the statistics
     assert two["wtd_mean_cm_last_row"] == one["wtd_mean_cm_last_row"]
     assert two["wtd_std_cm_last_row"] == one["wtd_std_cm_last_row"]
+
+
+def test_bench_five_ranks_share_the_card_and_reduce_to_the_one_rank_statistics():
+    """The N-rank path with more than two ranks on the one card a test box has (gloo; the box allows six processes on its GPU,
+    this test is the sixth): 5 x 512 members in contiguous blocks = 2 560 members on one rank, to the bit of the reduced
+    int64 moments; a sweep of 8 points dealt 2 + 2 + 2 + 1 + 1 assembles the table one rank computes.  (World size 8 is
+    rehearsed on CPU: tests/test_multigpu_cpu.py.)"""
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-sustained", "--no-heavy", "--no-n1e6"]
+    five = _run([sys.executable, "bench.py", "--gpus", "5", "--backend", "gloo", "--members", "512"] + common)
+    one = _run([sys.executable, "bench.py", "--members", "2560"] + common)
+    assert five["ranks"] == 5 and five["n_gpus"] == 5 and five["backend"] == "gloo"
+    assert five["members_in_reduced_moments"] == 5 * 512 == one["members_in_reduced_moments"]
+    assert five["moments_sha1"] == one["moments_sha1"]
+    assert five["wtd_mean_cm_last_row"] == one["wtd_mean_cm_last_row"] and five["wtd_std_cm_last_row"] == one["wtd_std_cm_last_row"]
+    sw = ["--workload", "sweep", "--points", "8", "--members", "64", "--steps", "1", "--warmup", "1"]
+    s5 = _run([sys.executable, "bench.py", "--gpus", "5", "--backend", "gloo"] + sw)
+    s1 = _run([sys.executable, "bench.py"] + sw)
+    assert s5["ranks"] == 5 and s5["config"]["points_per_gpu"] == 2
+    for line in (s5, s1):
+        a = line["sweep_assembled"]
+        assert a["points"] == 8 and a["points_complete_last_row"] == 8 and a["members_per_point_last_row_min_max"] == [64, 64]
+    assert s5["sweep_assembled"]["sha1"] == s1["sweep_assembled"]["sha1"]
 
 
 def test_bench_under_a_launcher_still_works():

@@ -383,14 +383,48 @@ def test_philox_run_matches_oracle_fed_with_the_same_normals(gpu):
 
 
 def test_spinup_on_gpu_reproduces_reference_initial_condition(gpu):
-    from hydromodel_amd.ensemble import spinup_on_gpu
+    """Simulation.initial_conditions (simulation.py:389-493) against the reference's own record of it (g1s_spinup_*: solves
+    used, the state after each of the first 12 solves, their solver statistics -- tests/golden/make_golden.py spinup):
+    the SAME number of solves, the first ten states at the chained-rows tier against the reference and at 1e-9 against the
+    oracle, the end state (~110 chained solves, chaotic last bits) within 0.02 cm."""
+    from hydromodel_amd.ensemble import pressure_head, spinup_on_gpu
     for well in (1, 200):
         _, cols, forcing = digest(well)
-        g = golden(f"g1_tables_{well}.npz")
+        g, gs = golden(f"g1_tables_{well}.npz"), golden(f"g1s_spinup_{well}.npz")
         n_rnd = np.random.default_rng(np.random.SeedSequence(911)).standard_normal(cols.dim_d)
         ic, iters, early = spinup_on_gpu(cols, forcing, n_rnd)
-        assert early and 100 <= iters <= 125
+        assert early and iters == int(gs["iterations"]), (well, iters, int(gs["iterations"]))   # 115 / 110 solves
         assert np.max(np.abs(ic - g["initial_cond"])) < 0.02
+        # the first solves, one by one
+        y0, _ = pressure_head(cols, cols.por_raw)
+        assert np.array_equal(y0, gs["y_start"])                                     # host plugin, bit-exact (G2)
+        st = gpu.EnsembleStepper(cols, forcing, 1)
+        st.set_state(y0)
+        st.set_noise_host(n_rnd[None, :])
+        o = _oracle(cols, forcing)
+        y_prev = y0.copy()
+        worst = {"regular vs oracle": 0.0, "stiff vs oracle": 0.0, "vs reference (chained)": 0.0}
+        for j in range(10):
+            out = st.step_rows(0, 1, spinup=True, moments=False, want_stats=True)
+            y_g = st.get_state()[0]
+            # the oracle on the SAME input (the kernel's previous state): one solve, the one-row tiers of DESIGN.md §3
+            y_o, s_o, _, _ = o.solve_row(_row(forcing, 0, spinup=True), 0.0, 1.0, y_prev, n_rnd.copy())
+            stiff = int(out["stats"][0, 0, 0]) > 100                      # solve 0: ~450 evaluations, ~135 steps from the hydrostatic start
+            e_o, e_r = rel_err(y_g, y_o), rel_err(y_g, gs["y_first"][j])
+            worst["stiff vs oracle" if stiff else "regular vs oracle"] = max(worst["stiff vs oracle" if stiff else "regular vs oracle"], e_o)
+            worst["vs reference (chained)"] = max(worst["vs reference (chained)"], e_r)
+            # solver statistics: the oracle's on the same input at every solve; the reference's own for solve 0, the one
+            # solve whose input is the reference's to the bit (after it the chains are ~1e-4 apart and a later solve may
+            # take a few evaluations more or fewer)
+            assert out["stats"][0, 0, :4].tolist() == [s_o[q] for q in ("nfev", "njev", "nlu", "nsteps")], (well, j)
+            if j == 0:
+                assert out["stats"][0, 0, :4].tolist() == gs["stats_first"][0].tolist(), well
+            assert e_o < (5e-3 if stiff else 1e-9), (well, j, e_o)
+            assert e_r < 5e-3, (well, j, e_r)                              # the reference's own chain of the ten solves
+            y_prev = y_g
+        print(f"[well {well}] spin-up: {iters} solves (reference {int(gs['iterations'])}); first ten solves, worst relative "
+              f"difference {worst}")
+        st.close()
 
 
 def test_full_size_day_properties(gpu):
@@ -453,6 +487,37 @@ def test_baseline_config3_full_size_day(gpu):
         r = o.run(forcing, g["initial_cond"], base, fresh, 1, 1 + rows)
         assert (out["wtd"][:, k] == r["wtd_est"][1:1 + rows]).mean() > 0.95
         assert np.max(np.abs(windows[131071][k - 131071] - r["psi"]) / (1 + np.abs(r["psi"]))) < 1e-3
+    st.close()
+
+
+def test_north_star_one_million_members_in_one_handle(gpu):
+    """BASELINE.json north_star: N = 1e6 at D = 300 on ONE GPU (1 048 576 members, 2.5 GB of state, one 48-row launch of
+    ~3 s), checked through the size-independent properties of the full-size tests: every row counts every member; the
+    int64 moments are finite sums in range; any 16-member window equals a stand-alone handle running exactly those global
+    member ids, bit for bit (`bench.py`'s `n1e6` leg times the same shape)."""
+    _, cols, forcing = digest(300)
+    g = golden("g1_tables_300.npz")
+    N, D, rows = 1048576, cols.dim_d, 48
+    st = gpu.EnsembleStepper(cols, forcing, N)
+    st.set_state(g["initial_cond"])
+    st.set_noise_philox(7, 0)
+    out = st.step_rows(1, rows)
+    m = st.moments()
+    assert out["launches"] == 1
+    assert np.array_equal(m[0, 1:1 + rows], np.full(rows, N))
+    assert (m[1, 1:1 + rows] >= 0).all() and (m[1, 1:1 + rows] <= N * (D - 1)).all()
+    assert (m[2, 1:1 + rows] >= m[1, 1:1 + rows]).all()                          # sum idx^2 >= sum idx for integer idx >= 0
+    for k in (0, 524287, N - 16):
+        y_big = st.get_state(first=k, count=16)
+        assert np.isfinite(y_big).all()
+        small = gpu.EnsembleStepper(cols, forcing, 16)
+        small.set_state(g["initial_cond"])
+        small.set_noise_philox(7, k)
+        small.step_rows(1, rows)
+        assert np.array_equal(small.get_state(), y_big), k
+        small.close()
+    print(f"1 048 576 members x 48 rows x D = 300 in one launch: {out['kernel_ms']:.0f} ms = "
+          f"{N / (out['kernel_ms'] * 1e-3):.0f} column-days/s")
     st.close()
 
 

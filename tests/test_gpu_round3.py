@@ -112,9 +112,14 @@ def test_whole_year_reference_oracle_and_gpu_side_by_side(gpu):
           f"{d_gr.max()} / {d_or.max()} / {d_go.max()} cells; rows that needed a retry: {retried}")
     assert d_gr.max() <= 1 and d_or.max() <= 1 and d_go.max() <= 1
     assert (d_gr[:1400] == 0).mean() > 0.98 and (d_or[:1400] == 0).mean() > 0.98
-    assert (d_or == 0).mean() >= 0.95            # measured 97.2 %
-    assert (d_gr == 0).mean() >= 0.90            # SURVEY §8c asked for >= 99 %: not reachable for ANY implementation
-    assert (d_go == 0).mean() >= 0.90            # once the retry rows differ (see the docstring); DESIGN.md §3
+    # SURVEY §8c asked for >= 99 %: not reachable for ANY implementation once the retry rows differ (see the docstring;
+    # DESIGN.md §3).  The gate is therefore RELATIVE to the faithful CPU restatement on this very run: the GPU may share
+    # at most 3 points less of the year with the reference than the oracle does (measured 96.4 % against 97.2 %), and the
+    # two of them agree with each other at least as well as the worse of them agrees with the reference, less 3 points.
+    e_gr, e_or, e_go = (float((d == 0).mean()) for d in (d_gr, d_or, d_go))
+    assert e_or >= 0.95                          # measured 97.2 %
+    assert e_gr >= e_or - 0.03, (e_gr, e_or)
+    assert e_go >= min(e_gr, e_or) - 0.03, (e_go, e_gr, e_or)
 
 
 def test_whole_year_equality_is_a_distribution_not_a_number(gpu):
@@ -444,14 +449,14 @@ def test_sweeps_deeper_than_576_nodes_run_on_the_split_column(gpu, monkeypatch):
     half of a pair and learnt by the lower half through the mailbox.  Properties: (i) each point of a three-point sweep is
     bit-equal -- states and moments -- to a stand-alone handle running that point with the same global member ids (also
     the split column); (ii) the sweep agrees with the same sweep on the one-wave kernels (HYDROCOL_SPLIT_COLUMN=0) within
-    the chained-rows tier; (iii) per-point counts are complete.  At 513..576 nodes sweeps stay on the one-wave kernel of 9
-    cells per lane (the faster one there since round 4), as single points do."""
+    the chained-rows tier; (iii) per-point counts are complete.  Round 5: the split column runs on the TWO layout (four
+    pairs per CU) and is the default from 513 nodes on, for sweeps as for single points -- D = 541 joins the depths."""
     from hydromodel_amd.digest import ColumnTables, ForcingDigest
     from hydromodel_amd.ensemble import SweepSimulation, check_sweep_points
     from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
     params = default_parameters()
     pts = [{"Soil_Properties": {"a0": 0.012}}, {"Soil_Properties": {"n": 2.0}}, {"Soil_Properties": {"n": 1.7, "psi_sat": -0.05}}]
-    for depth in (581, 640):
+    for depth in (541, 581, 640):
         cols_all = [ColumnTables(mp, synthetic_well(depth)) for mp in check_sweep_points(params, pts)]
         forcing = ForcingDigest(params, synthetic_forcing_frame(1), cols_all[0])
         psi0 = np.stack([c.z - 300.0 for c in cols_all])
@@ -467,7 +472,7 @@ def test_sweeps_deeper_than_576_nodes_run_on_the_split_column(gpu, monkeypatch):
             assert np.array_equal(one.stepper.get_state(), y[k * M:(k + 1) * M]), (depth, k)
             assert np.array_equal(one.moments()[0], mom[k]), (depth, k)
             one.close()
-        monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")        # the same sweep on the one-wave kernels of 10 cells per lane
+        monkeypatch.setenv("HYDROCOL_SPLIT_COLUMN", "0")        # the same sweep on the one-wave kernels of 9 / 10 cells per lane
         flat = SweepSimulation(cols_all, forcing, M, seed=2, psi0=psi0)
         flat.advance(rows)
         y1 = flat.stepper.get_state()

@@ -1,4 +1,4 @@
-"""The product's multi-GPU path on CPU (gloo, world size 2): member shards, sweep-result assembly, the CLI's self-launch.
+"""The product's multi-GPU path on CPU (gloo, world sizes 2 and 8): member shards, sweep-result assembly, the CLI's self-launch.
 
 Reference surface: /root/reference/code/berkeley_hydro_main.py:128-137 (one `sim.run(); sim.saveResults()`); here N ranks
 deliver one file (hydromodel_amd/multigpu.py, cli.py)."""
@@ -69,6 +69,49 @@ def test_sweep_assembly_world2_keeps_every_point_bit_for_bit(tmp_path, P):
             assert np.array_equal(g["m"][k], ref["moments"])
             assert np.array_equal(g["psi0"][k].view(np.int64), ref["psi0"].view(np.int64))      # to the bit
             assert int(g["spin"][k]) == ref["spinup_iterations"]
+
+
+@pytest.mark.parametrize("P", [512, 509])   # BASELINE configs[4] on 8 ranks; 509: ranks 5-7 are dealt one point fewer
+def test_sweep_assembly_world8_keeps_every_point_bit_for_bit(tmp_path, P):
+    world, T, D = 8, 7, 5
+    mp.spawn(_assemble_worker, args=(world, _free_port(), P, T, D, str(tmp_path), "ok"), nprocs=world, join=True)
+    deals = [len(deal_points(P, r, world)) for r in range(world)]
+    assert sum(deals) == P and max(deals) - min(deals) <= 1 and (P % world == 0 or deals[-1] == deals[0] - 1)
+    got = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    ref = [_fake_point(k, T, D) for k in range(P)]
+    for g in got:                                         # every one of the 8 ranks holds the whole table
+        assert np.array_equal(g["m"], np.stack([r["moments"] for r in ref]))
+        assert np.array_equal(g["psi0"].view(np.int64), np.stack([r["psi0"] for r in ref]).view(np.int64))
+        assert g["spin"].tolist() == [r["spinup_iterations"] for r in ref]
+
+
+def _shard_worker(rank, world, port, n_members, T, out_dir):
+    """What the ensemble path reduces: every rank's (count, sum idx, sum idx^2) rows over ITS member block."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HYDROCOL_DIST_BACKEND="gloo")
+    ranks = multigpu.Ranks(expect=world)
+    lo, hi = multigpu.shard(n_members, ranks.rank, ranks.world)
+    ids = np.arange(lo, hi, dtype=np.int64)
+    m = np.zeros((3, T), dtype=np.int64)
+    for t in range(T):                                    # a stand-in water-table index that depends on the GLOBAL member id
+        idx = (ids * 7 + t) % 300
+        m[:, t] = (ids.size, idx.sum(), (idx * idx).sum())
+    total = ranks.allreduce_sum(m)
+    if ranks.rank == 0:
+        np.save(os.path.join(out_dir, "total.npy"), total)
+    ranks.close()
+
+
+def test_member_shards_reduce_to_the_whole_ensemble_on_eight_ranks(tmp_path):
+    """configs[3]'s shape in small: 8 ranks, contiguous member blocks, ONE int64 all-reduce; the reduced count row must
+    read N on every row (what cli.py / bench.py check as `members_in_reduced_moments`), the sums those of one rank."""
+    world, N, T = 8, 4099, 6                              # 4099 = 8 x 512 + 3: three ranks own one member more
+    mp.spawn(_shard_worker, args=(world, _free_port(), N, T, str(tmp_path)), nprocs=world, join=True)
+    total = np.load(tmp_path / "total.npy")
+    ids = np.arange(N, dtype=np.int64)
+    for t in range(T):
+        idx = (ids * 7 + t) % 300
+        assert total[:, t].tolist() == [N, int(idx.sum()), int((idx * idx).sum())]
 
 
 def test_sweep_assembly_refuses_a_point_delivered_twice(tmp_path):

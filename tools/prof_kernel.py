@@ -10,6 +10,13 @@ import argparse, copy, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import numpy as np
+from hydromodel_amd import _lib
+if os.environ.get("HC_LIB"):          # a development build (tools/build_dev.py) instead of the shipped library
+    import pathlib
+    _lib.LIB_PATH = pathlib.Path(os.environ["HC_LIB"]).resolve()
+    import ctypes
+    _have = ctypes.CDLL(str(_lib.LIB_PATH))          # an older build lacks the newer entry points: bind what it has
+    _lib.EXPORTS = {k: v for k, v in _lib.EXPORTS.items() if hasattr(_have, k)}
 from hydromodel_amd.digest import ColumnTables, ForcingDigest
 from hydromodel_amd.ensemble import PHILOX_DRAW_SPINUP, spinup_on_gpu
 from hydromodel_amd.stepper import EnsembleStepper
