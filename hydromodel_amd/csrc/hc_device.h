@@ -19,7 +19,18 @@ namespace hc {
 constexpr int WAVE = 64;
 
 // slot tables staged in LDS, [NTAB][64*CPL] doubles
-enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, T_VALID, T_INVD1, NTAB };
+// T_RDELTA (round 5, -DHC_RDELTA_TABLE=1): the refined reciprocal of delta = por - theta_res, the divisor of the effective
+// saturation -- a constant of the cell that every evaluation otherwise recomputes (v_rcp_f64 + two Newton steps, 5 of the
+// ~94 VALU instructions of a cell, one of them a quarter-rate one).  Filled on the DEVICE (fill_rdelta in hydrocol.hip,
+// the same instruction sequence: the same bits), never by the host.
+#ifndef HC_RDELTA_TABLE
+#define HC_RDELTA_TABLE 0
+#endif
+#if HC_RDELTA_TABLE
+enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, T_VALID, T_INVD1, T_RDELTA, NTAB };
+#else
+enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, T_VALID, T_INVD1, NTAB, T_RDELTA = 0 };
+#endif
 // T_VALID = 1.0 in the slots of the D-1 midpoints, 0.0 beyond (a lane mask as data: a mask proper is an SGPR pair
 // the compiler spills and reloads with two v_readlane per use), T_INVD1 = 1/(por - wlt) (a zero denominator counts as 1)
 // per-slot integer tables, [NGTAB][64*CPL]
@@ -204,6 +215,15 @@ __device__ __forceinline__ double fast_rcp(double b)
     double r = __builtin_amdgcn_rcp(b);
     r = fma(fma(-b, r, 1.0), r, r);
     return fma(fma(-b, r, 1.0), r, r);
+}
+// the reciprocal the cell model divides by: fast_div's first five operations (model_cells_* spell them out per cell)
+__device__ __forceinline__ double refined_rcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double d = fma(-b, r, 1.0);
+    r = fma(d, r, r);
+    d = fma(-b, r, 1.0);
+    return fma(d, r, r);
 }
 // value of lane (byte_addr / 4) mod 64 -- raw ds_bpermute, no index arithmetic.  Callers pass
 // (lane +- d) * 4 and mask the lanes whose source falls outside the wave themselves.
@@ -587,11 +607,15 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     // s = (theta - theta_res) / delta   (the next table read is issued here, a division ahead of its use)
     HC_V(invm2[c] = tab[T_INVM2 * SLOTS + slot0 + c * WAVE])
     HC_V(a[c] = theta[c] - P.theta_res)
+#if HC_RDELTA_TABLE
+    HC_V(b[c] = tab[T_RDELTA * SLOTS + slot0 + c * WAVE])
+#else
     HC_V(b[c] = __builtin_amdgcn_rcp(delta[c]))
     HC_V(d[c] = fma(-delta[c], b[c], 1.0))
     HC_V(b[c] = fma(d[c], b[c], b[c]))
     HC_V(d[c] = fma(-delta[c], b[c], 1.0))
     HC_V(b[c] = fma(d[c], b[c], b[c]))
+#endif
     HC_V(d[c] = a[c] * b[c])
     HC_V(e[c] = fma(-delta[c], d[c], a[c]))
     HC_V(s[c] = fma(e[c], b[c], d[c]))
@@ -764,11 +788,15 @@ __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const do
     HC_V(theta[c] = sat[c] ? por[c] : y[c])
     // S_e = (theta - theta_res) / delta, clipped
     HC_V(y[c] = theta[c] - P.theta_res)
+#if HC_RDELTA_TABLE
+    HC_V(_b[c] = tab[T_RDELTA * SLOTS + slot0 + c * WAVE])
+#else
     HC_V(_b[c] = __builtin_amdgcn_rcp(delta[c]))
     HC_V(_d[c] = fma(-delta[c], _b[c], 1.0))
     HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))
     HC_V(_d[c] = fma(-delta[c], _b[c], 1.0))
     HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))
+#endif
     HC_V(_d[c] = y[c] * _b[c])
     HC_V(_e[c] = fma(-delta[c], _d[c], y[c]))
     HC_V(s[c] = fma(_e[c], _b[c], _d[c]))

@@ -102,6 +102,12 @@ constexpr int WAVE_SCRATCH = 160;
 #ifndef HC_TWO_PAIR
 #define HC_TWO_PAIR 1
 #endif
+#ifndef HC_TWO_J_FRESH         // the first factorisation after a Jacobian takes the rows from registers
+#define HC_TWO_J_FRESH 0
+#endif
+#ifndef HC_TWO_J_ALIAS         // Jacobian-phase vectors in the (then dead) factorisation's LDS slots: WaveVecs::ldJ
+#define HC_TWO_J_ALIAS 1
+#endif
 __host__ __device__ constexpr bool two_of(int cpl, int halves = 1, bool special = true)
 {
     if (halves == 2) return HC_TWO_PAIR && cpl == 5;
@@ -274,6 +280,25 @@ struct WaveVecs {
     {
         if (k < F_LDS) lds[TWO_LDS_ROWS * SLOTS + k * WAVE + lane] = v;
         else gst(F_OFF, ((k - F_LDS) * WAVE + lane) * 8, v);
+    }
+    // Round 5: while a Jacobian is being evaluated the factorisation is DEAD (every Jacobian ends with have_lu = 0), so its
+    // LDS slots hold the FD steps and as many Jacobian rows as fit (5 cells per lane: the steps + two rows in 15 of the 16
+    // slots; 4 cells: all four vectors) for the 6 - 7 phases that scatter into, re-read and finalise them.  The finished
+    // rows go to the global region once (later factorisations of the same Jacobian read them there); the FD steps die with
+    // the Jacobian.  ldJ / stJ: the Jacobian-phase view of a vector; ld / st stay the persistent one.
+    static constexpr int N_ALIAS = (TWO && HC_TWO_J_ALIAS) ? (F_LDS / CPL < 4 ? F_LDS / CPL : 4) : 0;
+    static constexpr int alias_of(int v) { return v == V_HJ ? 0 : v == V_JL ? 1 : v == V_JD ? 2 : v == V_JU ? 3 : 99; }
+    template <int VEC>
+    __device__ __forceinline__ double ldJ(int slot) const
+    {
+        if constexpr (alias_of(VEC) < N_ALIAS) return lds[(TWO_LDS_ROWS + alias_of(VEC)) * SLOTS + slot];
+        else return ld<VEC>(slot);
+    }
+    template <int VEC>
+    __device__ __forceinline__ void stJ(int slot, double v) const
+    {
+        if constexpr (alias_of(VEC) < N_ALIAS) lds[(TWO_LDS_ROWS + alias_of(VEC)) * SLOTS + slot] = v;
+        else st<VEC>(slot, v);
     }
     // lane-slot of each entry: wf[1..], wb[..CPL-3], l / u / 1/b [..CPL-2], then the 14 scalars
     static constexpr int K_WF = -1, K_WB = CPL - 1, K_L = 2 * CPL - 3, K_U = 3 * CPL - 4, K_IB = 4 * CPL - 5, K_S = 5 * CPL - 6;
@@ -894,7 +919,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #ifndef HC_TWO_JGATHER_MAX_CPL
 #define HC_TWO_JGATHER_MAX_CPL 4
 #endif
-    constexpr bool JG = TWO_J && CPL <= HC_TWO_JGATHER_MAX_CPL;
+    constexpr bool JG = TWO_J && CPL <= HC_TWO_JGATHER_MAX_CPL && !HC_TWO_J_ALIAS;   // (with the alias the scatter stays in LDS)
 #ifdef HC_TWO_NO_P_RELOAD
     constexpr bool P_RELOAD = false;
 #else
@@ -944,10 +969,10 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     } else if constexpr (TWO_J) {                                          \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
             const int s_ = c * WAVE + lane;                                \
-            jl[c] = W.template ld<V_JL>(s_);                               \
-            jd[c] = W.template ld<V_JD>(s_);                               \
-            ju[c] = W.template ld<V_JU>(s_);                               \
-            hj[c] = W.template ld<V_HJ>(s_);                               \
+            jl[c] = W.template ldJ<V_JL>(s_);                              \
+            jd[c] = W.template ldJ<V_JD>(s_);                              \
+            ju[c] = W.template ldJ<V_JU>(s_);                              \
+            hj[c] = W.template ldJ<V_HJ>(s_);                              \
         }                                                                  \
     }
 #define HC_J_STORE()                                                       \
@@ -962,10 +987,10 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     } else if constexpr (TWO_J) {                                          \
         _Pragma("unroll") for (int c = 0; c < CPL; c++) {                  \
             const int s_ = c * WAVE + lane;                                \
-            W.template st<V_JL>(s_, jl[c]);                                \
-            W.template st<V_JD>(s_, jd[c]);                                \
-            W.template st<V_JU>(s_, ju[c]);                                \
-            W.template st<V_HJ>(s_, hj[c]);                                \
+            W.template stJ<V_JL>(s_, jl[c]);                               \
+            W.template stJ<V_JD>(s_, jd[c]);                               \
+            W.template stJ<V_JU>(s_, ju[c]);                               \
+            W.template stJ<V_HJ>(s_, hj[c]);                               \
         }                                                                  \
     }
 // TWO layout: the three rows without the FD steps (a Jacobian's steps change only where they are computed), and the steps alone;
@@ -994,7 +1019,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     }
 #define HC_HJ_LOAD()                                                                               \
     if constexpr (TWO_J) {                                                                         \
-        _Pragma("unroll") for (int c = 0; c < CPL; c++) hj[c] = W.template ld<V_HJ>(c * WAVE + lane); \
+        _Pragma("unroll") for (int c = 0; c < CPL; c++) hj[c] = W.template ldJ<V_HJ>(c * WAVE + lane); \
     }
 // TWO layout: the factorisation is written once per lu_factor and read by every Newton iteration (no register of it is
 // live across an RHS evaluation); the predicted state / Jacobian base point likewise
@@ -1438,6 +1463,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                     // Phases run in topological order inside ONE loop iteration: a block that hands over to a
                     // later block falls through to it; only blocks that need a fresh RHS value end the iteration.
                     bool have_f = true;
+                    bool j_fresh = false;      // jl / jd / ju hold the Jacobian C_JAC_FIN has just finished (this trip)
                     if (phase == PH_F0 && have_f) {
                         have_f = false;
                         HC_STAMP(PH_F0);
@@ -1674,7 +1700,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                 }
                                 W.template st<V_FAC>(slot, fac);
                                 hj[c] = vnode[c] ? h : 1.0;
-                                if constexpr (TWO_J) W.template st<V_HJ>(slot, hj[c]);
+                                if constexpr (TWO_J) W.template stJ<V_HJ>(slot, hj[c]);
                             }
                             g = 0;
                         } else {
@@ -1689,16 +1715,16 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
 #pragma unroll
                                 for (int c = 0; c < CPL; c++) {
                                     const int s_ = c * WAVE + lane;
-                                    if (gp[c] == g) W.template st<V_JL>(s_, f[c]);
-                                    if (gs[c] == g) W.template st<V_JD>(s_, f[c]);
-                                    if (gn[c] == g) W.template st<V_JU>(s_, f[c]);
+                                    if (gp[c] == g) W.template stJ<V_JL>(s_, f[c]);
+                                    if (gs[c] == g) W.template stJ<V_JD>(s_, f[c]);
+                                    if (gn[c] == g) W.template stJ<V_JU>(s_, f[c]);
                                 }
                                 HC_HJ_LOAD();
                             } else if constexpr (JG) {
 #pragma unroll
                                 for (int c = 0; c < CPL; c++) {
                                     W.stG(g, c * WAVE + lane, f[c]);
-                                    hj[c] = W.template ld<V_HJ>(c * WAVE + lane);
+                                    hj[c] = W.template ldJ<V_HJ>(c * WAVE + lane);
                                 }
                             } else {
 #pragma unroll
@@ -1733,7 +1759,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                     jl[c] = W.ldG(gp[c] < 0 ? 0 : gp[c], s_);
                                     jd[c] = W.ldG(gs[c] < 0 ? 0 : gs[c], s_);
                                     ju[c] = W.ldG(gn[c] < 0 ? 0 : gn[c], s_);
-                                    hj[c] = W.template ld<V_HJ>(s_);
+                                    hj[c] = W.template ldJ<V_HJ>(s_);
                                 }
                             } else {
                                 HC_J_LOAD();        // after the retry pass: the rows as it left them
@@ -1823,6 +1849,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                                 if (vnode[c]) W.template st<V_FAC>(c * WAVE + lane, nfac[c]);
                             }
                             HC_J_STORE3();
+                            j_fresh = TWO_J && HC_TWO_J_ALIAS && HC_TWO_J_FRESH;
                                 jac_stage = 0;
                             if (jac_init) {
                                 // rest of BDF.__init__: D[0] = y, D[1] = f0 * h_abs, order = 1
@@ -1987,7 +2014,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         HC_STAMP(C_NEWTON_BEGIN);
                         if (!have_lu) {
                             HC_STAMP(23);
-                            HC_J_LOAD3();
+                            if (!j_fresh) { HC_J_LOAD3(); }      // (the rows as C_JAC_FIN stored them, unless it has just done so)
                             lu_factor<CPL>(F, jl, jd, ju, cc, lane, D, comm);
                             HC_F_STORE();
                             HC_STAMP(C_NEWTON_BEGIN);

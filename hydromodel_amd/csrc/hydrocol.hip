@@ -179,6 +179,16 @@ __global__ void widen_u16(const unsigned short *in, int *out, size_t n)
     if (k < n) out[k] = in[k];
 }
 
+#if HC_RDELTA_TABLE
+// T_RDELTA of every point: the refined reciprocal of por - theta_res, by the cell model's own instruction sequence
+__global__ void fill_rdelta(double *tab, const ColumnDev *P, int slots)
+{
+    double *t = tab + (size_t)blockIdx.x * NTAB * slots;
+    const double theta_res = P[blockIdx.x].theta_res;
+    for (int k = threadIdx.x; k < slots; k += blockDim.x)
+        t[(size_t)T_RDELTA * slots + k] = refined_rcp(t[(size_t)T_POR * slots + k] - theta_res);
+}
+#endif
 __global__ void fill_d(double *p, double v, size_t n)
 {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,6 +440,15 @@ int fill_args(hc_handle *h, StepArgs &A)
         }
         HIP_TRY(hipMemcpy(h->node_tabs.p, h->node_host.data(), h->node_host.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->Pdev.p, h->P_host.data(), (size_t)NP * sizeof(ColumnDev), hipMemcpyHostToDevice));
+#if HC_RDELTA_TABLE
+        {   // the reciprocal table is the device's own arithmetic (hc_device.h T_RDELTA)
+            const int S1 = WAVE * h->cpl;
+            hipLaunchKernelGGL(fill_rdelta, dim3((unsigned)NP), dim3(256), 0, h->stream, h->tab.p, h->Pdev.p, S1);
+            if (h->pair_ok)
+                hipLaunchKernelGGL(fill_rdelta, dim3((unsigned)NP), dim3(256), 0, h->stream, h->tab_pair.p, h->Pdev.p, 2 * WAVE * PAIR_CPL);
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+#endif
         h->points_dirty = false;
     }
     if (h->moments_points != NP) {      // one [3][T] table per point, zeroed when the number of points changes

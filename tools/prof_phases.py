@@ -45,7 +45,7 @@ assert st.lib.hc_debug_profile_subcounts(st.h, sub) == 0
 prof = [a - b for a, b in zip(prof, prof0)]; cnt = [a - b for a, b in zip(cnt, cnt0)]
 sub = [a - b for a, b in zip(sub, sub0)]
 names = {0: "PH_F0", 1: "PH_F1", 2: "PH_JAC", 3: "PH_JAC_REDO", 4: "PH_NEWTON", 5: "C_JAC_FIN", 6: "C_STEP_BEGIN",
-         7: "C_STEP_TRY", 8: "C_NEWTON_BEGIN", 9: "C_NEWTON_FAIL", 10: "C_ERR_TEST", 11: "C_ACCEPT", 16: "RHS prologue",
+         7: "C_STEP_TRY", 8: "C_NEWTON_BEGIN", 9: "C_NEWTON_FAIL", 10: "C_ERR_TEST", 11: "C_ACCEPT", 12: "PH_FBASE", 16: "RHS prologue",
          17: "post-RHS dispatch", 20: "newton: residual", 21: "newton: lu_solve", 22: "newton: norm+decide", 23: "lu_factor",
          24: "RHS cell model", 25: "RHS flux/hlift", 26: "RHS ET", 27: "RHS lateral flow", 28: "RHS top BC",
          29: "RHS assembly", 31: "loop top / outside"}
