@@ -69,6 +69,7 @@ EXPORTS = {
     "hc_set_generic_exponents": ([C.c_void_p, C.c_int32], C.c_int),
     "hc_set_rows_per_launch": ([C.c_void_p, C.c_int32], C.c_int),
     "hc_set_iteration_budget": ([C.c_void_p, C.c_int32], C.c_int),
+    "hc_set_scipy_152": ([C.c_void_p, C.c_int32], C.c_int),
     "hc_get_moments": ([C.c_void_p, _lp], C.c_int),
     "hc_export_moments": ([C.c_void_p, C.c_void_p], C.c_int),
     "hc_set_moments": ([C.c_void_p, _lp], C.c_int),

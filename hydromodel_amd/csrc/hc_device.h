@@ -19,17 +19,27 @@ namespace hc {
 constexpr int WAVE = 64;
 
 // slot tables staged in LDS, [NTAB][64*CPL] doubles
-// T_RDELTA (round 5, -DHC_RDELTA_TABLE=1): the refined reciprocal of delta = por - theta_res, the divisor of the effective
-// saturation -- a constant of the cell that every evaluation otherwise recomputes (v_rcp_f64 + two Newton steps, 5 of the
-// ~94 VALU instructions of a cell, one of them a quarter-rate one).  Filled on the DEVICE (fill_rdelta in hydrocol.hip,
-// the same instruction sequence: the same bits), never by the host.
+// T_RDELTA (round 5): the refined reciprocal of delta = por - theta_res, the divisor of the effective saturation -- a constant
+// of the cell that every evaluation otherwise recomputes (v_rcp_f64 + two Newton steps: 5 of the ~94 VALU instructions of a
+// cell, one of them a quarter-rate one).  Filled on the DEVICE (fill_rdelta in hydrocol.hip: the same instruction sequence,
+// the same bits), never by the host.  It is the LAST table: the kernels that do not read it stage the first NTAB - 1 only.
+// Read where it pays (rdelta_table below): up to 5 cells per lane on one wave per member, +2.1 ... 2.5 % at D = 300 and +1.5 % at
+// 241; at 6 cells per lane the LDS it takes from the factorisation costs more than it saves (-5 %), the split column is as
+// short of LDS.  -DHC_RDELTA_TABLE=0: nobody reads it (A/B builds).
 #ifndef HC_RDELTA_TABLE
-#define HC_RDELTA_TABLE 0
+#define HC_RDELTA_TABLE 1
 #endif
-#if HC_RDELTA_TABLE
 enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, T_VALID, T_INVD1, T_RDELTA, NTAB };
-#else
-enum { T_POR = 0, T_FC, T_WLT, T_ROOT, T_LOGM, T_INVM2, T_NOISEC, T_VALID, T_INVD1, NTAB, T_RDELTA = 0 };
+// `slots` = table row stride = 64 x cells per lane x waves per member
+// (the generic-exponent cell model, twice the working set, LOSES 12 % with the table at 5 cells per lane: default exponents only)
+__host__ __device__ constexpr bool rdelta_table(int slots, bool special = true) { return HC_RDELTA_TABLE && special && slots <= 64 * 5; }
+__host__ __device__ constexpr int ntab_lds(int slots, bool special = true) { return rdelta_table(slots, special) ? (int)NTAB : (int)NTAB - 1; }
+// round 5: masks as factors in the ET sums, the lateral-flow total only when it is asked for (+0.5 ... 2.3 %, same bits).  In
+// the two-waves-per-SIMD kernels only (compiled with -ffp-contract=on: source-determined bits); the one-wave kernels are
+// compiled with hipcc's default contraction, where ANY change of the code's shape may move a fusion decision and with it
+// last bits (it did: the digests at D = 401 ... 512 changed with this edit and came back without it), so they keep their code.
+#ifndef HC_RHS_DIET
+#define HC_RHS_DIET 1
 #endif
 // T_VALID = 1.0 in the slots of the D-1 midpoints, 0.0 beyond (a lane mask as data: a mask proper is an SGPR pair
 // the compiler spills and reloads with two v_readlane per use), T_INVD1 = 1/(por - wlt) (a zero denominator counts as 1)
@@ -607,15 +617,15 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     // s = (theta - theta_res) / delta   (the next table read is issued here, a division ahead of its use)
     HC_V(invm2[c] = tab[T_INVM2 * SLOTS + slot0 + c * WAVE])
     HC_V(a[c] = theta[c] - P.theta_res)
-#if HC_RDELTA_TABLE
-    HC_V(b[c] = tab[T_RDELTA * SLOTS + slot0 + c * WAVE])
-#else
-    HC_V(b[c] = __builtin_amdgcn_rcp(delta[c]))
-    HC_V(d[c] = fma(-delta[c], b[c], 1.0))
-    HC_V(b[c] = fma(d[c], b[c], b[c]))
-    HC_V(d[c] = fma(-delta[c], b[c], 1.0))
-    HC_V(b[c] = fma(d[c], b[c], b[c]))
-#endif
+    if constexpr (rdelta_table(SLOTS)) {
+        HC_V(b[c] = tab[T_RDELTA * SLOTS + slot0 + c * WAVE])
+    } else {
+        HC_V(b[c] = __builtin_amdgcn_rcp(delta[c]))
+        HC_V(d[c] = fma(-delta[c], b[c], 1.0))
+        HC_V(b[c] = fma(d[c], b[c], b[c]))
+        HC_V(d[c] = fma(-delta[c], b[c], 1.0))
+        HC_V(b[c] = fma(d[c], b[c], b[c]))
+    }
     HC_V(d[c] = a[c] * b[c])
     HC_V(e[c] = fma(-delta[c], d[c], a[c]))
     HC_V(s[c] = fma(e[c], b[c], d[c]))
@@ -788,15 +798,11 @@ __device__ __forceinline__ void model_cells_generic(const ColumnDev &P, const do
     HC_V(theta[c] = sat[c] ? por[c] : y[c])
     // S_e = (theta - theta_res) / delta, clipped
     HC_V(y[c] = theta[c] - P.theta_res)
-#if HC_RDELTA_TABLE
-    HC_V(_b[c] = tab[T_RDELTA * SLOTS + slot0 + c * WAVE])
-#else
     HC_V(_b[c] = __builtin_amdgcn_rcp(delta[c]))
     HC_V(_d[c] = fma(-delta[c], _b[c], 1.0))
     HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))
     HC_V(_d[c] = fma(-delta[c], _b[c], 1.0))
     HC_V(_b[c] = fma(_d[c], _b[c], _b[c]))
-#endif
     HC_V(_d[c] = y[c] * _b[c])
     HC_V(_e[c] = fma(-delta[c], _d[c], y[c]))
     HC_V(s[c] = fma(_e[c], _b[c], _d[c]))
@@ -967,6 +973,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                                          double (&f)[CPL], double *aux, double &diag_tr, double &diag_lf, CommT &comm HC_RHS_PROF_PARAM)
 {
     constexpr int H = CommT::H;
+    constexpr bool DIET = ONE_BALLOT && HC_RHS_DIET;           // (ONE_BALLOT = "a two-waves-per-SIMD kernel": see HC_RHS_DIET)
     constexpr int SLOTS = WAVE * CPL * H;                      // table row stride
     const int hb = H == 2 ? comm.half * (WAVE * CPL) : 0;      // index of this wave's first node
     const bool last_half = H == 1 || comm.half == H - 1;
@@ -1079,14 +1086,29 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                 t_invd1[c] = tab[T_INVD1 * SLOTS + slot];
                 t_root[c] = tab[T_ROOT * SLOTS + slot];
             }
+            if constexpr (DIET) {
+                // the root-zone mask as a 0 / 1 factor: fma(m, x, s) rounds x + s exactly as the masked add does (m = 1) and
+                // returns s (m = 0, x finite) -- one instruction per term instead of two selects and an add
 #pragma unroll
-            for (int c = 0; c < CPL; c++) {
-                const int i = lane * CPL + c;
-                isr[c] = int(i >= 1) & int(i <= P.n_root_int);
-                const double dw = th[c] - t_wlt[c];
-                s_w += isr[c] ? dw : 0.0;
-                s_t += isr[c] ? th[c] : 0.0;
-                pre[c] = s_t;
+                for (int c = 0; c < CPL; c++) {
+                    const int i = lane * CPL + c;
+                    isr[c] = int(i >= 1) & int(i <= P.n_root_int);
+                    const double m = isr[c] ? 1.0 : 0.0;
+                    const double dw = th[c] - t_wlt[c];
+                    s_w = fma(m, dw, s_w);
+                    s_t = fma(m, th[c], s_t);
+                    pre[c] = s_t;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    const int i = lane * CPL + c;
+                    isr[c] = int(i >= 1) & int(i <= P.n_root_int);
+                    const double dw = th[c] - t_wlt[c];
+                    s_w += isr[c] ? dw : 0.0;
+                    s_t += isr[c] ? th[c] : 0.0;
+                    pre[c] = s_t;
+                }
             }
             // one pass: exclusive scan of the lane totals of theta (grand total from its last lane) + sum of s_w
             double excl = s_t, tot_theta, sum_w = s_w;
@@ -1267,10 +1289,21 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
                 const int p = hb + lane * CPL + c - 1;
                 const bool in = (p >= wtd_est) && (p < wtd_obs);
                 sk[c] = in ? fmin(-2.5e-4 * ym[c], sk[c]) : sk[c];
-                s_l += in ? fabs(sk[c]) : 0.0;
+                if constexpr (!DIET) s_l += in ? fabs(sk[c]) : 0.0;
             }
             if (H == 2 && hb - 2 >= wtd_est && hb - 2 < wtd_obs) edge_s = fmin(-2.5e-4 * edge_ym, edge_s);
-            if (R.diag) diag_lf = comm.sum(s_l) * P.dz;   // richards_pde.py:374,388
+            if constexpr (DIET) {
+                if (R.diag) {   // the sink's total is a diagnostic: summed only when asked for (richards_pde.py:374,388)
+#pragma unroll
+                    for (int c = 0; c < CPL; c++) {
+                        const int p = hb + lane * CPL + c - 1;
+                        s_l += ((p >= wtd_est) && (p < wtd_obs)) ? fabs(sk[c]) : 0.0;
+                    }
+                    diag_lf = comm.sum(s_l) * P.dz;
+                }
+            } else {
+                if (R.diag) diag_lf = comm.sum(s_l) * P.dz;   // richards_pde.py:374,388
+            }
         }
     }
     // ---- top boundary, richards_pde.py:414-476 (computed in lane 63's spare slot)

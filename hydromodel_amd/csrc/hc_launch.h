@@ -21,7 +21,7 @@ struct LaunchCfg {
 inline size_t step_lds_bytes(int cpl, int wpb, int halves = 1, bool special = true)
 {
     const size_t slots = (size_t)WAVE * cpl;
-    return (NTAB * slots * 8 + 4 * slots * 1) * halves +
+    return ((size_t)ntab_lds((int)slots * halves, special) * slots * 8 + 4 * slots * 1) * halves +
            (size_t)wpb * ((size_t)lds_wave_doubles(cpl, halves, special) + WAVE_SCRATCH) * 8 +
            (halves == 2 ? (size_t)(wpb / 2) * sizeof(PairBox) : 0);
 }

@@ -139,7 +139,7 @@ constexpr int LDS_BYTES = 160 * 1024;
 __host__ __device__ constexpr int lds_wave_bytes(int cpl, int halves = 1, bool special = true)
 {
     const int slots = 64 * cpl;
-    const int tables = (NTAB * slots * 8 + 4 * slots) * halves;
+    const int tables = (ntab_lds(slots * halves, special) * slots * 8 + 4 * slots) * halves;
     const int wpb = wpb_of(cpl, halves, special);
     const int boxes = halves == 2 ? (wpb / 2) * (int)sizeof(PairBox) : 0;
     return (LDS_BYTES - tables - boxes) / wpb - WAVE_SCRATCH * 8;
@@ -176,7 +176,7 @@ __host__ __device__ constexpr int lds_extra(int cpl, int halves = 1, bool specia
     //  is an AGPR move, cheaper than the LDS round trip)
     if (halves != 1 || wpb_of(cpl, halves, special) != 8) return 0;
     const int slots = 64 * cpl;
-    const int tables = NTAB * slots * 8 + 4 * slots;
+    const int tables = ntab_lds(slots, special) * slots * 8 + 4 * slots;
     const int n = ((LDS_BYTES - tables) / wpb_of(cpl, halves, special) - WAVE_SCRATCH * 8) / (slots * 8);
     return n >= NVEC + 4 ? 4 : 0;
 }
@@ -430,6 +430,9 @@ struct StepArgs {
     int spin_stop;
     double spin_zwtd, spin_z0, spin_dz;
     int max_phase_iterations; // MAX_PHASE_ITERATIONS (test hook: HYDROCOL_DEBUG_MAX_ITER lowers it to force abandoned attempts)
+    // select_initial_step as the reference's pinned scipy==1.5.2 has it: neither h0 nor the returned step is clamped to the
+    // interval (scipy >= 1.9 clamps both; 1.15.3 made the pinning vectors and is the default).  hc_set_scipy_152.
+    int scipy_152;
     // parameter points (BASELINE config 5): P[n_points], tab[n_points][NTAB][SLOTS]; members are point-major, point k owns
     // members [k * members_per_point, (k + 1) * members_per_point).  With more than one point a workgroup works through
     // chunks of `chunk_members` members of ONE point (its tables sit in LDS); chunk c = (point c / chunks_per_point,
@@ -869,7 +872,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     constexpr int TSLOTS = SLOTS * HALVES;
     extern __shared__ double lds[];
     double *tab = lds;
-    signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB * TSLOTS);     // group ids < 16: a byte each
+    constexpr int NTAB_L = ntab_lds(TSLOTS, SPECIAL);         // tables this kernel stages (the last one, T_RDELTA, only where it is read)
+    signed char *gtab = reinterpret_cast<signed char *>(tab + NTAB_L * TSLOTS);     // group ids < 16: a byte each
     double *wave_base = reinterpret_cast<double *>(gtab + 4 * TSLOTS);
     constexpr int NVEC_K = lds_vectors(CPL, HALVES, SPECIAL);
     constexpr int NEXTRA = lds_extra(CPL, HALVES, SPECIAL);
@@ -937,7 +941,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
     const bool multi = (HALVES == 1 || PMULTI) && A.n_points > 1;      // (round 4: the split column serves several points too)
 #endif
     if (!multi)
-        for (int k = threadIdx.x; k < NTAB * TSLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
+        for (int k = threadIdx.x; k < NTAB_L * TSLOTS; k += WPB * WAVE) tab[k] = A.tab[k];
     for (int k = threadIdx.x; k < NGTAB * TSLOTS; k += WPB * WAVE) gtab[k] = (signed char)A.gtab[k];
     if (threadIdx.x == 0) {
         chunk_state[0] = 0;
@@ -1217,7 +1221,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
             const int pt = __builtin_amdgcn_readfirstlane(chunk_state[3]);
             if (pt != __builtin_amdgcn_readfirstlane(chunk_state[2])) {
                 const double *src = A.tab + (size_t)pt * (NTAB * TSLOTS);
-                for (int k = threadIdx.x; k < NTAB * TSLOTS; k += WPB * WAVE) tab[k] = src[k];
+                for (int k = threadIdx.x; k < NTAB_L * TSLOTS; k += WPB * WAVE) tab[k] = src[k];
                 __syncthreads();
                 if (threadIdx.x == 0) chunk_state[2] = pt;   // next read: after the first barrier of the next chunk change
             }
@@ -1481,7 +1485,7 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                         const double d0 = rms_ratio<CPL>(y0v, scl, lane, D, inv_sqrt_d, comm);
                         const double d1 = rms_ratio<CPL>(f, scl, lane, D, inv_sqrt_d, comm);
                         h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-                        h0 = fmin(h0, fabs(tf - t0));
+                        h0 = A.scipy_152 ? h0 : fmin(h0, fabs(tf - t0));
                         cc = d1;                              // carried to PH_F1
 #pragma unroll
                         for (int c = 0; c < CPL; c++) {
@@ -1506,7 +1510,8 @@ __global__ __launch_bounds__(WPB * WAVE, WPB / 4) void step_kernel(const StepArg
                             h1 = fmax(1e-6, h0 * 1e-3);
                         else
                             h1 = sqrt(0.01 / fmax(d1, d2));
-                        h_abs = fmin(fmin(100.0 * h0, h1), fabs(tf - t0));
+                        h_abs = fmin(100.0 * h0, h1);
+                        h_abs = A.scipy_152 ? h_abs : fmin(h_abs, fabs(tf - t0));    // (1.5.2: _step_impl's t_bound rule takes care of it)
                         // first Jacobian: num_jac at (t0, y0) with f0 (the reference re-evaluates f0; same value)
                         njev++;
                         jac_init = 1;

@@ -109,6 +109,7 @@ struct hc_handle {
     DevBuf<int> spin_iters;
     DevBuf<double> trace;        // diagnostic builds only
     int max_phase_iterations = MAX_PHASE_ITERATIONS;
+    int scipy_152 = 0;           // hc_set_scipy_152
     bool strict_guard = false;   // HYDROCOL_STRICT_GUARD=1: a tripped iteration guard fails the call
     DevBuf<int> gtab, wtd_obs, draw_idx, stats, scratch_i;
     DevBuf<unsigned char> daylight, refresh;
@@ -179,7 +180,6 @@ __global__ void widen_u16(const unsigned short *in, int *out, size_t n)
     if (k < n) out[k] = in[k];
 }
 
-#if HC_RDELTA_TABLE
 // T_RDELTA of every point: the refined reciprocal of por - theta_res, by the cell model's own instruction sequence
 __global__ void fill_rdelta(double *tab, const ColumnDev *P, int slots)
 {
@@ -188,7 +188,6 @@ __global__ void fill_rdelta(double *tab, const ColumnDev *P, int slots)
     for (int k = threadIdx.x; k < slots; k += blockDim.x)
         t[(size_t)T_RDELTA * slots + k] = refined_rcp(t[(size_t)T_POR * slots + k] - theta_res);
 }
-#endif
 __global__ void fill_d(double *p, double v, size_t n)
 {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -440,7 +439,6 @@ int fill_args(hc_handle *h, StepArgs &A)
         }
         HIP_TRY(hipMemcpy(h->node_tabs.p, h->node_host.data(), h->node_host.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->Pdev.p, h->P_host.data(), (size_t)NP * sizeof(ColumnDev), hipMemcpyHostToDevice));
-#if HC_RDELTA_TABLE
         {   // the reciprocal table is the device's own arithmetic (hc_device.h T_RDELTA)
             const int S1 = WAVE * h->cpl;
             hipLaunchKernelGGL(fill_rdelta, dim3((unsigned)NP), dim3(256), 0, h->stream, h->tab.p, h->Pdev.p, S1);
@@ -448,7 +446,6 @@ int fill_args(hc_handle *h, StepArgs &A)
                 hipLaunchKernelGGL(fill_rdelta, dim3((unsigned)NP), dim3(256), 0, h->stream, h->tab_pair.p, h->Pdev.p, 2 * WAVE * PAIR_CPL);
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
-#endif
         h->points_dirty = false;
     }
     if (h->moments_points != NP) {      // one [3][T] table per point, zeroed when the number of points changes
@@ -491,6 +488,7 @@ int fill_args(hc_handle *h, StepArgs &A)
     A.psi_sat = h->P.psi_sat;
     A.jac_reject = h->jac_reject;
     A.max_phase_iterations = h->max_phase_iterations;
+    A.scipy_152 = h->scipy_152;
     io.psi = h->psi.p;
     io.base_noise = h->philox ? nullptr : h->base.p;
     io.nscale = h->nscale.p;
@@ -589,6 +587,7 @@ int hc_create(int device_ordinal, hc_handle **out)
         h->no_split = atoi(sc) == 0;
         h->force_split = atoi(sc) == 1;
     }
+    if (const char *sv = getenv("HYDROCOL_SCIPY_152")) h->scipy_152 = atoi(sv) != 0;     // (the whole product at once: CLI, Simulation)
     if (const char *mi = getenv("HYDROCOL_DEBUG_MAX_ITER"))    // test hook: forces abandoned attempts
         if (atoi(mi) > 0) h->max_phase_iterations = atoi(mi);
     const char *jr = getenv("HYDROCOL_DEBUG_JAC_REJECT");   // test hook: exercises num_jac's retry branch
@@ -1346,6 +1345,13 @@ int hc_set_iteration_budget(hc_handle *h, int32_t phase_steps)
 {
     if (!h || phase_steps < 1) return fail(HC_ERR_ARG, "hc_set_iteration_budget: bad argument");
     h->max_phase_iterations = phase_steps;
+    return HC_OK;
+}
+
+int hc_set_scipy_152(hc_handle *h, int32_t on)
+{
+    if (!h) return fail(HC_ERR_ARG, "hc_set_scipy_152: NULL handle");
+    h->scipy_152 = on ? 1 : 0;
     return HC_OK;
 }
 

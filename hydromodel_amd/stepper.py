@@ -225,6 +225,10 @@ class EnsembleStepper:
     def set_iteration_budget(self, phase_steps):
         L.check(self.lib.hc_set_iteration_budget(self.h, int(phase_steps)))
 
+    def set_scipy_152(self, on=True):
+        """``select_initial_step`` as the reference's pinned scipy==1.5.2 has it (no clamp to the interval); default: scipy >= 1.9."""
+        L.check(self.lib.hc_set_scipy_152(self.h, int(bool(on))))
+
     def reset_moments(self):
         L.check(self.lib.hc_reset_moments(self.h))
 

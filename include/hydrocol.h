@@ -205,6 +205,12 @@ int hc_get_counters(hc_handle *h, uint64_t *out4);
 int hc_set_rows_per_launch(hc_handle *h, int32_t rows);
 /* Budget of one BDF attempt in trips of the kernel's phase loop (>= 1). */
 int hc_set_iteration_budget(hc_handle *h, int32_t phase_steps);
+/* The integrator is SciPy's (third-party to the reference; /root/reference/requirements.txt:4 pins scipy==1.5.2, the pinning
+ * vectors were made with 1.15.3).  On this path the two differ in ONE place: common.py select_initial_step clamps h0 and
+ * the step it returns to the integration interval since scipy 1.9.  Default (0): the >= 1.9 form; on != 0: the 1.5.2 form
+ * (also HYDROCOL_SCIPY_152=1 in the environment at hc_create).  How often the clamps bind and what that moves:
+ * profiles/r05_scipy152_clamp.txt. */
+int hc_set_scipy_152(hc_handle *h, int32_t on);
 
 /* moments: [n_points][3][n_forcing_rows] int64 = count, sum(idx), sum(idx^2) of wtd_est over the members of each
  * parameter point ([3][n_forcing_rows] for the usual single point); not available for spin-up solves */

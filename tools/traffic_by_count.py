@@ -9,7 +9,8 @@ E = dict(att=1.00, jac=1.00, grp=5.00, lu=3.73, nwt=12.22, stp=6.11, rise=0.18, 
 
 def layout(cpl, halves=1):
     slots = 64 * cpl
-    tables = (NTAB * slots * 8 + 4 * slots) * halves
+    ntab = NTAB + (1 if slots * halves <= 320 else 0)        # + the reciprocal table where the cell model reads it (hc_device.h rdelta_table)
+    tables = (ntab * slots * 8 + 4 * slots) * halves
     boxes = 4 * BOX if halves == 2 else 0
     per_wave = (LDS_BYTES - tables - boxes) // 8 - SCRATCH
     nf = 5 * cpl + 8 + (cpl + 1 if halves == 2 else 0)
