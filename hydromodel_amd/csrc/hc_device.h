@@ -38,6 +38,11 @@ __host__ __device__ constexpr int ntab_lds(int slots, bool special = true) { ret
 // the two-waves-per-SIMD kernels only (compiled with -ffp-contract=on: source-determined bits); the one-wave kernels are
 // compiled with hipcc's default contraction, where ANY change of the code's shape may move a fusion decision and with it
 // last bits (it did: the digests at D = 401 ... 512 changed with this edit and came back without it), so they keep their code.
+// two selects of the default-exponent cell model replaced by exact identities (+0.4 ... 0.7 %, same bits; two-wave kernels only,
+// like HC_RHS_DIET below)
+#ifndef HC_MODEL_DIET
+#define HC_MODEL_DIET 1
+#endif
 #ifndef HC_RHS_DIET
 #define HC_RHS_DIET 1
 #endif
@@ -589,7 +594,7 @@ __device__ __forceinline__ void model_cell(const ColumnDev &P, double psi, doubl
 #endif
 #define HC_V(...)                         \
     _Pragma("unroll") for (int c = 0; c < N; c++) { __VA_ARGS__; }
-template <int N, int SLOTS>
+template <int N, int SLOTS, bool DIET = false>
 __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const double *tab, int slot0,
                                                     const double *psi, const double *rnd, double *theta, double *K,
                                                     double *C, double *kbo, double *pfac)
@@ -636,8 +641,15 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     HC_V(b[c] = __builtin_amdgcn_frexp_mant(a[c]))
     HC_V(ex[c] = __builtin_amdgcn_frexp_exp(a[c]))
     HC_V(lo[c] = b[c] < 0.70710678118654752440)
-    HC_V(b[c] = lo[c] ? b[c] + b[c] : b[c])
-    HC_V(ex[c] = lo[c] ? ex[c] - 1 : ex[c])
+    if constexpr (DIET) {   // b + b = ldexp(b, 1), ex - 1: the flag as an integer feeds both (one select instead of three)
+        int lo_i[N];
+        HC_V(lo_i[c] = lo[c] ? 1 : 0)
+        HC_V(b[c] = ldexp(b[c], lo_i[c]))
+        HC_V(ex[c] = ex[c] - lo_i[c])
+    } else {
+        HC_V(b[c] = lo[c] ? b[c] + b[c] : b[c])
+        HC_V(ex[c] = lo[c] ? ex[c] - 1 : ex[c])
+    }
     HC_V(f[c] = b[c] - 1.0)
     HC_V(a[c] = 2.0 + f[c])
     HC_V(b[c] = __builtin_amdgcn_rcp(a[c]))
@@ -676,6 +688,8 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     HC_V(g[c] = fma(d[c], h[c], g[c]))
     HC_V(d[c] = fma(-g[c], g[c], Lt[c]))
     HC_V(g[c] = fma(d[c], h[c], g[c]))
+    // (capping rsq at 1e300 instead of this select is exact too and two instructions shorter, but measured -1.7 % at D = 300,
+    //  +1.6 % at 241: the compiler's placement, not the instruction count, decides at this size -- left alone)
     HC_V(g[c] = Lt[c] == 0.0 ? 0.0 : g[c])
     // kb = exp_mid(sig * rnd - Lt / 2 + log m)
     HC_V(a[c] = fma(g[c], rnd[c], fma(-0.5, Lt[c], logm[c])))
@@ -698,7 +712,13 @@ __device__ __forceinline__ void model_cells_special(const ColumnDev &P, const do
     HC_V(b[c] = ldexp(b[c], (int)dk[c]))
     HC_V(kbo[c] = noisec[c] < 0.0 ? P.sat_soil : b[c])   // cell in no layer: vrettas_fung.py:143
     HC_V(a[c] = s[c] * kbo[c])                           // <= kb: np.minimum(K, kbkg) is a no-op
-    HC_V(K[c] = sat[c] ? kbo[c] : a[c])
+    if constexpr (DIET) {
+        // A saturated cell has theta = por, so theta - theta_res IS delta bit for bit and the division above returns exactly
+        // 1.0 (q = delta r = 1 + e, the correction -delta e r brings it to 1 - e e' -> 1.0): s kb = kb, no select needed
+        HC_V(K[c] = a[c])
+    } else {
+        HC_V(K[c] = sat[c] ? kbo[c] : a[c])
+    }
     // C = m n alpha delta s^3 (alpha |psi|), epsilon when saturated / below epsilon / not finite
     HC_V(a[c] = s[c] * s[c] * s[c])
     HC_V(a[c] = P.mn_alpha * delta[c] * a[c] * ap[c])
@@ -974,6 +994,7 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
 {
     constexpr int H = CommT::H;
     constexpr bool DIET = ONE_BALLOT && HC_RHS_DIET;           // (ONE_BALLOT = "a two-waves-per-SIMD kernel": see HC_RHS_DIET)
+    constexpr bool MDIET = ONE_BALLOT && HC_MODEL_DIET;
     constexpr int SLOTS = WAVE * CPL * H;                      // table row stride
     const int hb = H == 2 ? comm.half * (WAVE * CPL) : 0;      // index of this wave's first node
     const bool last_half = H == 1 || comm.half == H - 1;
@@ -1020,10 +1041,10 @@ __device__ __forceinline__ void rhs_eval(const ColumnDev &P, const RowDev &R, co
             constexpr int NB = CPL / B, REM = CPL - NB * B;
 #pragma unroll
             for (int q = 0; q < NB; q++)
-                model_cells_special<B, SLOTS>(P, tab, q * B * WAVE + lane, ym + q * B, rnd + q * B, th + q * B,
-                                              Kc + q * B, Cc + q * B, kbv + q * B, pfv + q * B);
+                model_cells_special<B, SLOTS, MDIET>(P, tab, q * B * WAVE + lane, ym + q * B, rnd + q * B, th + q * B,
+                                                     Kc + q * B, Cc + q * B, kbv + q * B, pfv + q * B);
             if (REM > 0)
-                model_cells_special<(REM > 0 ? REM : 1), SLOTS>(P, tab, NB * B * WAVE + lane, ym + NB * B, rnd + NB * B,
+                model_cells_special<(REM > 0 ? REM : 1), SLOTS, MDIET>(P, tab, NB * B * WAVE + lane, ym + NB * B, rnd + NB * B,
                                                                 th + NB * B, Kc + NB * B, Cc + NB * B, kbv + NB * B,
                                                                 pfv + NB * B);
         } else {

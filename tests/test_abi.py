@@ -86,7 +86,7 @@ def test_every_kernel_unit_is_built_and_the_scheduler_table_names_real_units():
     assert set(ge.UNIT_FLAGS) <= units
     for groups in ge.UNIT_FLAGS.values():
         for group in groups:
-            assert group in (("-ffp-contract=on",), ("-DHC_MODEL_BATCH=4",)) or \
+            assert group in (("-ffp-contract=on",), ("-DHC_MODEL_BATCH=4",), ("-DHC_GENERIC_BATCH=4",)) or \
                 (len(group) == 2 and group[0] == "-mllvm" and group[1].startswith("-amdgpu-"))
     # the units compiled as TWO-layout kernels are exactly the ones with source-determined contraction
     two = {k for k, groups in ge.UNIT_FLAGS.items() if ("-ffp-contract=on",) in groups}
