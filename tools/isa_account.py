@@ -23,7 +23,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(R, "hydromodel_amd", "csrc")
 
 REGION_NAMES = {0: "PH_F0", 1: "PH_F1", 2: "PH_JAC", 3: "PH_JAC_REDO", 4: "PH_NEWTON", 5: "C_JAC_FIN", 6: "C_STEP_BEGIN",
-                7: "C_STEP_TRY", 8: "C_NEWTON_BEGIN", 9: "C_NEWTON_FAIL", 10: "C_ERR_TEST", 11: "C_ACCEPT",
+                7: "C_STEP_TRY", 8: "C_NEWTON_BEGIN", 9: "C_NEWTON_FAIL", 10: "C_ERR_TEST", 11: "C_ACCEPT", 12: "PH_FBASE",
                 16: "RHS prologue", 17: "post-RHS dispatch", 20: "newton: residual", 21: "newton: lu_solve",
                 22: "newton: norm+decide", 23: "lu_factor", 24: "RHS cell model", 25: "RHS flux/hlift", 26: "RHS ET",
                 27: "RHS lateral flow", 28: "RHS top BC", 29: "RHS assembly", 31: "loop top", -1: "outside the phase loop",
@@ -126,11 +126,31 @@ def regions_of(path, kernel):
     return per
 
 
+def phases_text(path):
+    """Entries and cycles per region out of the table tools/prof_phases.py prints (the committed profiles/r0N_phases_*.txt)."""
+    by_name = {v.strip(): k for k, v in REGION_NAMES.items()}
+    by_name["loop top / outside"] = 31
+    entries, cycles = {}, {}
+    lines = open(path).read().splitlines()
+    for line in lines:
+        m = re.match(r"^(.+?)\s+([0-9.]+)%\s+(\d+)\s+([0-9.]+)\s+(\d+)\s*$", line)
+        if m and m.group(1).strip() in by_name:
+            k = by_name[m.group(1).strip()]
+            entries[str(k)], cycles[str(k)] = float(m.group(4)), float(m.group(3))
+        if line.startswith("sub-region entries per column-step:"):
+            for part in line.split(":", 1)[1].split(","):
+                name, val = part.strip().rsplit(" ", 1)
+                if name in by_name:
+                    entries[str(by_name[name])] = float(val)
+    return {"entries_per_column_step": entries, "cycles_per_column_step": cycles, "source": lines[0].strip() + " -- " + path}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpl", type=int, default=5)
     ap.add_argument("--kernel", default=None, help="mangled-name prefix after _ZN2hc11 (default: the special monitoring kernel)")
     ap.add_argument("--dynamic", default=None, help="JSON of tools/prof_phases.py --json (entries and cycles per region)")
+    ap.add_argument("--phases", default=None, help="text output of tools/prof_phases.py (profiles/r05_phases_d300.txt) instead of --dynamic")
     ap.add_argument("--asm", default=None, help="use this .s file instead of compiling")
     ap.add_argument("-D", action="append", default=[], help="extra -D for the compile")
     args = ap.parse_args()
@@ -152,9 +172,12 @@ def main():
     valu = sum(total[c] for c in VALU_CLASSES)
     print(f"{'TOTAL':28s} {sum(total.values()):6.0f} {valu:6.0f} {total['f64 arith'] + total['f64 trans']:6.0f} | "
           + " ".join(f"{total[c]:14.0f}" for c in classes))
-    if not args.dynamic:
+    if args.phases:
+        dyn = phases_text(args.phases)
+    elif args.dynamic:
+        dyn = json.load(open(args.dynamic))
+    else:
         return
-    dyn = json.load(open(args.dynamic))
     entries = {int(k): v for k, v in dyn["entries_per_column_step"].items()}
     cycles = {int(k): v for k, v in dyn["cycles_per_column_step"].items()}
     print(f"\n# dynamic estimate per column-step = static instructions of a region x its measured entries "
