@@ -44,6 +44,7 @@ FABRIC_PEAK_GBPS = 8600.0       # ... its measured Infinity-Cache gather rate (3
                                 # L2 <-> fabric counters of a cache-resident working set are priced against
 HBM_ACHIEVABLE_GBPS = 6290.0    # ... its measured streaming rate (float4 copy)
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
+VALU_ISSUE_SLOTS_PER_S = 256 * 4 * 2.4e9 / 4.0   # 1024 SIMDs, one 64-lane fp64 VALU instruction per 4 cycles at the peak clock
 # Per-kernel constants from rocprofv3 PMC passes: profiles/pmc_constants.json (written by tools/pmc_constants.py from the
 # counter CSVs it names), keyed by "<depth>/<cell model>" and valid for ONE device-code identity (hc_version()'s kernel
 # hash: kernel sources + compile flags + compiler).  A library built from other kernel code gets traffic: null -- counters
@@ -240,6 +241,24 @@ def n1e6_leg(cols, forcing, psi0, members, days, seed, device):
     return out
 
 
+def valu_object(column_steps_per_s, pmc, source):
+    """The fp64 vector unit, two ways: flop against the FMA peak, and issue slots -- the kernel's VALU wave instructions (fp64
+    arithmetic or not) against one instruction per SIMD per 4 cycles, the bound that binds here."""
+    if not pmc:
+        return None
+    tflops = column_steps_per_s * pmc["f64_flop_per_column_step"] / 1e12
+    out = {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s per GPU", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+           "source": source}
+    insts = pmc.get("valu_wave_instructions_per_column_step")
+    if insts:
+        arith = sum(pmc["f64_wave_instructions_per_column_step"].values())
+        out["issue"] = {"valu_wave_instructions_per_column_step": insts, "fp64_arithmetic_share": arith / insts,
+                        "frac_of_issue_slots": column_steps_per_s * insts / VALU_ISSUE_SLOTS_PER_S,
+                        "what": "SQ_INSTS_VALU per column-step x column-steps/s over 1024 SIMDs x 2.4 GHz / 4 cycles; every VALU "
+                                "instruction priced at 4 cycles (fp64 transcendentals take 16), the clock at its peak"}
+    return out
+
+
 def roofline_object(bytes_per_launch, launch_ms, per_launch_ms, launches, pmc, pmc_why, members, rows_per_launch, kernel,
                     note):
     """The `roofline` entry of the JSON line.  `achieved` = algorithmic bytes / mean launch time against the HBM peak (the
@@ -399,12 +418,9 @@ def run_sweep(args, rank, world, dev, dist):
                                     rows_per_launch, "hc::step_kernel<5, generic exponents> (rank 0)",
                                     "fp64-VALU/recurrence bound (SURVEY.md §8d); the costliest points set the pace; "
                                     "counter constants are those of the n = 1.7 point"),
-        "valu_f64": ({"achieved": (col_days / elapsed) * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world,
-                      "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
-                      "frac": (col_days / elapsed) * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world
-                      / FP64_VALU_PEAK_TFLOPS,
-                      "source": "fp64 instruction mix per column-step of the n = 1.7 point from rocprofv3 PMC (profiles/README.md); "
-                                "costlier points do more"} if pmc else None),
+        "valu_f64": valu_object((col_days / elapsed) * ROWS_PER_DAY / world, pmc,
+                                "fp64 instruction mix per column-step of the n = 1.7 point from rocprofv3 PMC (profiles/README.md); "
+                                "costlier points do more"),
         "sweep_rank0": {"spinup_s": spin_s, "spinup_iterations_max": int(np.max(np.abs(sim.spinup_iters))),
                         "spinup_capped": int((np.asarray(sim.spinup_iters) < 0).sum()),
                         "failed_attempts": cnt["failed_attempts"], "guard_trips": cnt["guard_trips"],
@@ -520,12 +536,8 @@ def run_ensemble(args, rank, world, dev, dist):
                                     "the path is fp64-VALU/recurrence bound (SURVEY.md §8d, `valu_f64` below): ~19 RHS "
                                     "evaluations per column-step at ~10^2 flop per byte of state; psi stays on chip "
                                     "for the 48 rows of a launch"),
-        "valu_f64": ({"achieved": value * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world,
-                      "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
-                      "frac": value * ROWS_PER_DAY * pmc["f64_flop_per_column_step"] / 1e12 / world
-                      / FP64_VALU_PEAK_TFLOPS,
-                      "source": "fp64 instruction mix per column-step from rocprofv3 PMC (profiles/README.md)"}
-                     if pmc else None),
+        "valu_f64": valu_object(value * ROWS_PER_DAY / world, pmc,
+                                "fp64 instruction mix per column-step from rocprofv3 PMC (profiles/README.md)"),
         "moments_allreduce_s": allreduce_s, "members_in_reduced_moments": members_seen,
         # identity of the reduced statistics: equal at any rank count (integer sums keyed by global member ids)
         "moments_sha1": __import__("hashlib").sha1(np.ascontiguousarray(np.asarray(moments)[:, :last_row + 1]).tobytes()).hexdigest(),

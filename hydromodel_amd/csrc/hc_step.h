@@ -89,8 +89,12 @@ constexpr int WAVE_SCRATCH = 160;
 // re-read per evaluation (P_RELOAD below); 6 / 7 / 8 cells 0.84 / 0.77 / 0.49x (LDS holds 5 / 4 / 3 vectors a wave) --
 // after the traffic cuts 6 cells 0.91x with the cell model in one batch of 5 + 1 and 1.065x in batches of 4 + 2
 // (-DHC_MODEL_BATCH=4 for that unit, __graft_entry__.UNIT_FLAGS), 7 cells 0.91x at best, generic 6 cells 0.97x.
+// Round 5, late: with the spills gone (machine LICM off + sink-to-avoid-spills, __graft_entry__.UNIT_FLAGS) SEVEN cells per lane pay
+// too -- D = 401 (the reference's default well) 199.5 k against 182.5 k column-days/s on the one-wave kernel built the same way
+// (174 k before), D = 448 the same; EIGHT cells 0.74 - 0.81x (LDS holds 3 of 48 factorisation slots); generic exponents at 7
+// cells 1.03x at best: left on the one-wave kernel (gpurun_out/r5x, r5y).
 #ifndef HC_TWO_MASK
-#define HC_TWO_MASK ((1 << 4) | (1 << 5) | (1 << 6))      // default exponents: bit per cells-per-lane count
+#define HC_TWO_MASK ((1 << 4) | (1 << 5) | (1 << 6) | (1 << 7))      // default exponents: bit per cells-per-lane count
 #endif
 #ifndef HC_TWO_MASK_GENERIC
 #define HC_TWO_MASK_GENERIC ((1 << 4) | (1 << 5) | (1 << 6))   // generic exponents (6 cells: 0.97x in round 4, 1.034x with round 5's placement)

@@ -52,6 +52,13 @@ def test_bench_contract_one_rank():
         assert f["unit"] == "GB/s" and f["peak"] == 8600.0 and f["hbm_achievable"] == 6290.0
         assert abs(f["achieved"] - r["traffic"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-6 * f["achieved"]
         assert abs(f["traffic_over_algorithmic"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 1e-9
+        # the bound that binds: VALU wave instructions of the counter pass against one per SIMD per 4 cycles
+        k = consts["kernels"]["300/special"]
+        iss = out["valu_f64"]["issue"]
+        assert iss["valu_wave_instructions_per_column_step"] == k["valu_wave_instructions_per_column_step"]
+        slots = out["value"] * 48 * iss["valu_wave_instructions_per_column_step"] / (1024 * 2.4e9 / 4)
+        assert abs(iss["frac_of_issue_slots"] - slots) < 1e-9 and 0.0 < slots < 1.0
+        assert 0.5 < iss["fp64_arithmetic_share"] < 0.8
     else:
         assert r["traffic"] is None and r["fabric"] is None and "re-run tools/gpu_r5_pmc.sh" in r["traffic_source"]
     # per-launch spread of the timed steps (one launch per step at this size)

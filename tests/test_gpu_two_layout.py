@@ -30,10 +30,11 @@ def _digests(lib, depths, members):
 def test_one_wave_and_two_wave_builds_of_the_same_source_agree_to_the_bit(tmp_path):
     import __graft_entry__ as ge
     ge.build()
-    # the kernels of 5 cells per lane (D = 257..320: the bench's depth) with the TWO layout switched off
-    one_wave = ge.build_library(tmp_path / "lib_one_wave.so", cpls=(5,), obj_dir=tmp_path / "obj", force=True,
-                                defines=("-DHC_CPL_MASK=32", "-DHC_TWO_MASK=0", "-DHC_TWO_MASK_GENERIC=0"))
-    depths, members = [261, 300, 320], 3000          # 3 000 members: the 1-ulp difference of `fast` builds showed in ~1 member of 1 000
+    # the kernels of 5 cells per lane (D = 257..320: the bench's depth) and of 7 (D = 385..448: the reference's default well; on
+    # the TWO layout since late round 5) with the layout switched off
+    one_wave = ge.build_library(tmp_path / "lib_one_wave.so", cpls=(5, 7), obj_dir=tmp_path / "obj", force=True,
+                                defines=("-DHC_CPL_MASK=160", "-DHC_TWO_MASK=0", "-DHC_TWO_MASK_GENERIC=0"))
+    depths, members = [261, 300, 320, 401], 3000     # 3 000 members: the 1-ulp difference of `fast` builds showed in ~1 member of 1 000
     a = _digests(ge.CSRC / "libhydrocol.so", depths, members)
     b = _digests(one_wave, depths, members)
     assert a == b, (a, b)

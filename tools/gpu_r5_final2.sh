@@ -11,6 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench
 timeout -k 10 600 python3 bench.py --workload sweep > $OUT/bench_sweep.json 2> $OUT/bench_sweep.err; echo "sweep rc $?"
 timeout -k 10 300 python3 tools/prof_phases.py tools/dev/_ab/lib_prof_two.so 8192 > $OUT/phases_d300.txt 2>&1
 HC_PROF_D=581 timeout -k 10 300 python3 tools/prof_phases.py tools/dev/_ab/lib_prof_two.so 4096 > $OUT/phases_d581.txt 2>&1
+timeout -k 10 600 python3 -m pytest tests/test_gpu_bench.py -m gpu -q 2>&1 | tail -3
 find $OUT -name "*_agent_info.csv" -delete
 find $OUT -type f -size +4M -delete
 python3 - <<PY

@@ -12,6 +12,8 @@ from hydromodel_amd.digest import ColumnTables, ForcingDigest
 from hydromodel_amd.ensemble import EnsembleSimulation
 from hydromodel_amd.synthetic import default_parameters, synthetic_forcing_frame, synthetic_well
 params = default_parameters()
+if os.environ.get("HC_PROF_SOIL_N"):                 # a generic-exponent kernel instead (n = 2 is the specialised one)
+    params["Soil_Properties"]["n"] = float(os.environ["HC_PROF_SOIL_N"])
 frame = synthetic_forcing_frame(1)
 for D in map(int, sys.argv[2:]):
     cols = ColumnTables(params, synthetic_well(D))

@@ -50,6 +50,7 @@ def table(cpl, halves=1):
 def main():
     print(__doc__)
     for cpl, halves, what in ((4, 1, "D = 193..256"), (5, 1, "D = 257..320, the bench"), (6, 1, "D = 321..384"),
+                              (7, 1, "D = 385..448, the reference's default well; default exponents only"),
                               (5, 2, "split column, D = 513..640: per HALF")):
         L, rows = table(cpl, halves)
         total = sum(r[2] for r in rows)
