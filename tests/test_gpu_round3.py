@@ -585,7 +585,7 @@ def test_first_days_of_the_deepest_reference_well_replay_on_the_split_column_ker
     """96 rows recorded inside the reference's own run at its deepest well (no. 14, max_depth 2 900 cm, D = 581;
     `make_golden.py deep`), each replayed from the reference's input state and noise vector through the split-column
     kernel: the two-wave layout against the reference itself, not only against the oracle.  The same for the well the
-    reference's input_parameters.json selects (no. 10, D = 401: the 7-cells-per-lane one-wave kernel)."""
+    reference's input_parameters.json selects (no. 10, D = 401: the 7-cells-per-lane kernel: one wave per SIMD until late round 5, the TWO layout since)."""
     _, cols, forcing = digest(well)
     g = golden(fname)
     st = gpu.EnsembleStepper(cols, forcing, 1)
@@ -603,7 +603,7 @@ def test_first_days_of_the_deepest_reference_well_replay_on_the_split_column_ker
     errs = np.array(errs)
     tiers = {"<1e-9": int((errs < 1e-9).sum()), "1e-9..1e-6": int(((errs >= 1e-9) & (errs < 1e-6)).sum()),
              ">=1e-6 (loose)": int((errs >= 1e-6).sum())}
-    print(f"[D={well}] {len(errs)} reference rows on the {'split-column' if well > 512 else 'one-wave'} kernel: {same} with the reference's "
+    print(f"[D={well}] {len(errs)} reference rows on the {'split-column' if well > 512 else 'two-waves-per-SIMD' if well <= 448 else 'one-wave'} kernel: {same} with the reference's "
           f"nfev/njev/nlu/steps/attempts; tiers {tiers}")
     assert same >= 0.9 * len(errs), (same, len(errs))
     assert tiers[">=1e-6 (loose)"] < 0.2 * len(errs), tiers
