@@ -103,6 +103,7 @@ def test_a_hipcc_without_a_tuning_option_still_builds_the_unit(tmp_path, monkeyp
     monkeypatch.setenv("HYDROCOL_REJECT_MLLVM", "-amdgpu-use-amdgpu-trackers,-sink-insts-to-avoid-spills")
     monkeypatch.setattr(ge, "_FLAG_OK", {})
     assert ge.unit_flags_for((9, 0)) == [] and ge.unit_tuning_flags((9, 0)) == []
+    assert ge.unit_flags_for((8, 0)) == ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
     assert ge.unit_flags_for((8, 1)) == []                          # (machine LICM off goes with the sink option or not at all)
     assert ge.unit_flags_for((3, 1)) == ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"]       # others untouched
     assert ge.unit_flags_for((5, 1)) == ["-ffp-contract=on"]                                        # never dropped
