@@ -934,11 +934,16 @@ int hc_philox_normals(hc_handle *h, int64_t member, int64_t draw, double *out)
     return HC_OK;
 }
 
-// One simulated day per launch for large ensembles; small ones get proportionally longer launches, so that a launch
-// still holds ~64 k member-days of work and the tail behind its slowest wavefront stays small (include/hydrocol.h).
-static int auto_rows_per_launch(int64_t n_members)
+// One simulated day per launch for very large ensembles; smaller ones get proportionally longer launches, so that a launch
+// holds ~1 M member-days of work (in-kernel noise; round 5: 64 k before) and the tail behind its slowest wavefront stays
+// small: 4 096 members x D = 200 over the year 308.5 k column-days/s at 16 days per launch, 319 k at 64, 324 k at 128, 327 k at
+// 364; 65 536 members 324 k at 1 day, 331 k at 4, 334 k at 16; 16 384 members 286 k at 4 days, 292 k at 64
+// (gpurun_out/r5zd).  With the caller's noise every refreshed row of a launch stages members x D doubles on the device:
+// there the launches stay at ~64 k member-days (include/hydrocol.h).
+static int auto_rows_per_launch(int64_t n_members, bool in_kernel_noise)
 {
-    const int64_t days = std::max<int64_t>(1, std::min<int64_t>(65536 / std::max<int64_t>(n_members, 1), 365));
+    const int64_t target = in_kernel_noise ? (int64_t(1) << 20) : 65536;
+    const int64_t days = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(n_members, 1), 365));
     return (int)(48 * days);
 }
 
@@ -972,7 +977,7 @@ int hc_step_rows(hc_handle *h, hc_step_args *a)
     if (a->wtd_out) out_bytes_per_row += N * 4;
     const int64_t rows_cap = out_bytes_per_row > 0 ? std::max<int64_t>(1, (int64_t(1) << 30) / out_bytes_per_row) : INT32_MAX;
     for (int64_t done = 0; done < a->n_rows;) {
-        int per_launch = h->rows_per_launch > 0 ? h->rows_per_launch : auto_rows_per_launch(N);
+        int per_launch = h->rows_per_launch > 0 ? h->rows_per_launch : auto_rows_per_launch(N, h->philox);
         if (h->rows_per_launch <= 0) per_launch = (int)std::min<int64_t>(per_launch, rows_cap);
         const int chunk = (int)std::min<int64_t>(per_launch, a->n_rows - done);
         const int64_t row0 = a->spinup ? a->row_begin : a->row_begin + done;

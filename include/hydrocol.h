@@ -194,9 +194,10 @@ int hc_synchronize(hc_handle *h);
  * (members per scheduling chunk when several parameter points share a launch), HYDROCOL_DEBUG_CUS (a persistent grid of
  * fewer workgroups than the device has compute units: measurements only). */
 int hc_get_counters(hc_handle *h, uint64_t *out4);
-/* Rows one kernel launch of hc_step_rows covers; hc_step_rows splits longer requests.  Default (and rows = 0): 48 = one
- * simulated day for ensembles of >= 65 536 members, proportionally more for smaller ones (48 x 65 536 / members, at
- * most a year).
+/* Rows one kernel launch of hc_step_rows covers; hc_step_rows splits longer requests.  Default (and rows = 0): with the
+ * in-kernel noise 48 = one simulated day for ensembles of >= 1 048 576 members, proportionally more for smaller ones
+ * (48 x 1 048 576 / members, at most a year; round 5: 65 536 before -- 4 096 members +5 %, 16 384 +2 %, 65 536 +3 %); with
+ * the caller's noise (every refreshed row of a launch stages members x D doubles) 48 x 65 536 / members.
  * A member's rows of a launch are solved back to back by one wavefront with psi resident in LDS, and a launch ends when
  * its slowest wavefront does.  Large ensembles (>> 1 024 wavefronts' worth of members) balance within a day; a SMALL
  * ensemble (a few members per wavefront, e.g. 4 096) loses ~15 % to that tail per launch and is better served by long

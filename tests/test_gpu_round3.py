@@ -614,7 +614,7 @@ def test_first_days_of_the_deepest_reference_well_replay_on_the_split_column_ker
 def test_config2_at_full_size_whole_year(gpu):
     """BASELINE configs[1] at its size: 4 096 members x D = 200 through the WHOLE 1-year forcing (17 519 rows).  Properties
     that do not depend on the size: every solved row counts every member; the per-row moments do not depend on how the
-    year is cut into launches (the library's choice for this ensemble -- 16 days per launch -- against 5-day launches);
+    year is cut into launches (the library's choice for this ensemble -- 256 days per launch since round 5 -- against 5-day launches);
     the first members equal a small stand-alone handle; states stay finite and the water table stays on the grid."""
     _, cols, forcing = digest(200)
     ic = golden("g1_tables_200.npz")["initial_cond"]

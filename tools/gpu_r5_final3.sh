@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${1:-r5j3}
 mkdir -p $OUT
 cd $ROOT
-timeout -k 10 500 python3 tools/dev/cfg2_bench.py 48 4380 17472 > $OUT/cfg2.json 2>&1; cat $OUT/cfg2.json
+timeout -k 10 500 python3 tools/dev/cfg2_bench.py 0 48 17472 > $OUT/cfg2.json 2>&1; cat $OUT/cfg2.json
 timeout -k 10 400 python3 tools/soak.py 65536 300 1 > $OUT/soak_65536_d300_1yr.txt 2>&1; tail -3 $OUT/soak_65536_d300_1yr.txt
 timeout -k 10 300 python3 tools/soak.py 16384 581 1 > $OUT/soak_16384_d581_1yr.txt 2>&1; tail -3 $OUT/soak_16384_d581_1yr.txt
 timeout -k 10 300 python3 tools/soak.py 32768 200 1 > $OUT/soak_32768_d200_1yr.txt 2>&1; tail -3 $OUT/soak_32768_d200_1yr.txt
