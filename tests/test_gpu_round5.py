@@ -56,3 +56,36 @@ def test_scipy_152_initial_step_switch_matches_the_oracle_switch(well):
     assert same_stats >= 0.95 * len(rows)
     assert np.median(errs_old) < 1e-8 and np.quantile(errs_old, 0.95) < 1e-5 and errs_old.max() < 5e-2      # the one-row tiers
     assert differ >= 5                                                # the switch does something: the h0 clamp binds often
+
+
+def test_automatic_launch_length_follows_the_noise_mode_and_leaves_the_results_alone():
+    """Late round 5 (include/hydrocol.h, hc_set_rows_per_launch): with the in-kernel noise a request is cut into launches of ~1 M
+    member-days (the tail behind a launch's slowest wavefront: profiles/r05_launch_length_policy.txt), with the caller's noise --
+    every refreshed row of a launch stages members x D doubles on the device -- into ~64 k member-days as before.  The per-row
+    moments and the end state do not depend on the cut."""
+    from hydromodel_amd.stepper import EnsembleStepper
+    _, cols, forcing = digest(1)
+    ic = golden("g1_tables_1.npz")["initial_cond"]
+    N, rows = 16384, 48 * 6                                   # 6 days: 1 M / 16 384 = 64 days, 64 k / 16 384 = 4 days per launch
+    res = []
+    for rpl in (0, 48):
+        st = EnsembleStepper(cols, forcing, N)
+        if rpl:
+            st.set_rows_per_launch(rpl)
+        st.set_state(ic)
+        st.set_noise_philox(11, 0)
+        out = st.step_rows(1, rows)
+        res.append((out["launches"], st.moments()[:, :rows + 1].copy(), st.get_state(0, 16)))
+        st.close()
+    assert res[0][0] == 1 and res[1][0] == 6
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    # the caller's noise: 4 days per launch at this size -> 2 launches for the 6 days
+    n_fresh = int(forcing.refresh[1:rows + 1].sum())
+    rng = np.random.default_rng(5)
+    M = 2048                                                  # (64 k / 2 048 = 32 days per launch: one launch; 16 384 members would
+    st = EnsembleStepper(cols, forcing, M)                    #  need 16 384 x D x n_fresh doubles of host noise for nothing more)
+    st.set_state(ic)
+    st.set_noise_host(rng.standard_normal((M, cols.dim_d)))
+    out = st.step_rows(1, 48 * 40, fresh_noise=rng.standard_normal((int(forcing.refresh[1:48 * 40 + 1].sum()), M, cols.dim_d)))
+    st.close()
+    assert out["launches"] == 2 and n_fresh >= 1              # 40 days at 32 days per launch (in-kernel noise: 365 days -> 1)
