@@ -38,3 +38,19 @@ def test_one_wave_and_two_wave_builds_of_the_same_source_agree_to_the_bit(tmp_pa
     a = _digests(ge.CSRC / "libhydrocol.so", depths, members)
     b = _digests(one_wave, depths, members)
     assert a == b, (a, b)
+
+
+def test_the_compile_settings_of_late_round_5_do_not_change_a_bit(tmp_path):
+    """`__graft_entry__.UNIT_FLAGS` compiles the two-wave units with machine LICM off, MachineSink's sink-to-avoid-spills and
+    (some) the AMDGPU register-pressure trackers: options that act after instruction selection, i.e. on placement and schedule
+    only (profiles/r05_compile_flags_by_unit.txt: identical digests in every A/B block).  Kept as a test: a build of the same
+    units with NONE of the tuning options -- only `-ffp-contract=on`, which is part of the semantics -- must end in the same
+    states to the bit at the bench's depth, the default well's and on the split column."""
+    import __graft_entry__ as ge
+    ge.build()
+    plain = ge.build_library(tmp_path / "lib_plain.so", cpls=(5, 7), obj_dir=tmp_path / "obj", force=True, unit_flags=False,
+                             defines=("-DHC_CPL_MASK=160", "-ffp-contract=on"))
+    depths, members = [300, 401, 581], 3000
+    a = _digests(ge.CSRC / "libhydrocol.so", depths, members)
+    b = _digests(plain, depths, members)
+    assert a == b, (a, b)
